@@ -1,0 +1,140 @@
+/*
+ * vyolo.h — C-ABI of libvyolo.so, the MI355X-native yolo3_darknet53 hot path.
+ *
+ * The reference has no FFI: its "operator API" for this path is the duck-typed surface of the
+ * Gluon HybridBlock that models/definitions/yolo/wrappers.py:9-110 (yolo3_darknet53) returns,
+ * as driven by train_yolov3.py and detect_yolo3.py.  Each entry point below names the reference
+ * call it stands in for (paths relative to /root/reference).  The Python class that presents
+ * the Gluon surface over these entry points is videoyolo_amd/model.py; INTEGRATION.md shows the
+ * ctypes stub a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - plain C types only; every function returns 0 on success or a negative vy_status and
+ *     leaves a message for vy_last_error() (thread-local).
+ *   - the library never allocates or frees device memory and never synchronises the device
+ *     inside a forward/step call: the caller owns three device buffers per net
+ *     (parameters, workspace, and — for training — gradients/momentum), sized by the vy_*_bytes
+ *     queries, and passes the HIP stream to launch on (hipStream_t as void*; NULL = default).
+ *   - one vy_net per device / rank / stream; a net holds no global state.
+ *   - tensors at the boundary use the reference's layouts: images NCHW fp32, conv weights OIHW,
+ *     detections (ids (B,post_nms,1), scores (B,post_nms,1), bboxes (B,post_nms,4)) fp32 with
+ *     -1 filler, exactly what YOLOV3T.hybrid_forward returns (yolo3.py:1203-1206).
+ */
+#ifndef VYOLO_H
+#define VYOLO_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct vy_net vy_net;
+
+enum vy_status {
+  VY_OK = 0,
+  VY_ERR_INVALID = -1,      /* bad argument / unsupported configuration */
+  VY_ERR_STATE = -2,        /* call order: buffers not bound, not planned, ... */
+  VY_ERR_HIP = -3,          /* a HIP runtime call or kernel launch failed */
+  VY_ERR_UNSUPPORTED = -4   /* reference feature outside the hot path (temporal variants ...) */
+};
+
+enum vy_param_kind {
+  VY_P_WEIGHT = 0, VY_P_GAMMA = 1, VY_P_BETA = 2, VY_P_RUNNING_MEAN = 3, VY_P_RUNNING_VAR = 4,
+  VY_P_BIAS = 5
+};
+
+/* One row of collect_params() (train_yolov3.py:494-497, wrappers.py:55-57). */
+typedef struct vy_param_info {
+  char name[96];        /* gluon structural name, e.g. "stages.0.2.body.1.0.weight" */
+  int32_t kind;         /* vy_param_kind */
+  int32_t ndim;         /* 4 for conv weights (O,I,kh,kw), else 1 */
+  int32_t shape[4];     /* reference shape */
+  int64_t size;         /* element count */
+  int64_t offset;       /* element offset of this tensor inside the device parameter buffer
+                           (device layout: conv weights are stored O,kh,kw,I) */
+  int32_t trainable;    /* 0 for running_mean / running_var */
+  int32_t backbone;     /* 1 if the tensor belongs to the Darknet-53 stages (freeze_base) */
+} vy_param_info;
+
+/* Last error message of the calling thread ("" if none). */
+const char* vy_last_error(void);
+
+/* Library build id ("vyolo <n> gfx950"). */
+const char* vy_version(void);
+
+/* yolo3_darknet53(classes, ...) at k=1 — wrappers.py:9-12,54-58,80-84,101-103 and
+ * YOLOV3T.__init__ yolo3.py:959-1054.  num_class = len(classes). */
+int vy_net_create(int32_t num_class, vy_net** out);
+void vy_net_destroy(vy_net* net);
+
+/* net.set_nms(nms_thresh, nms_topk, post_nms) — yolo3.py:1208-1228.  nms_topk <= 0 selects
+ * every valid candidate (capped at VY_MAX_TOPK); post_nms <= 0 returns nms_topk rows. */
+#define VY_MAX_TOPK 1024
+int vy_net_set_nms(vy_net* net, float nms_thresh, int32_t nms_topk, int32_t post_nms);
+
+/* collect_params(): number of tensors, and row i. */
+int32_t vy_net_num_params(const vy_net* net);
+int vy_net_param_info(const vy_net* net, int32_t i, vy_param_info* out);
+
+/* Bytes of the device parameter buffer (all tensors + folded-BN scratch). */
+size_t vy_net_param_bytes(const vy_net* net);
+/* Bind the caller-owned device parameter buffer (net.collect_params().reset_ctx(ctx),
+ * detect_yolo3.py:199). */
+int vy_net_bind_params(vy_net* net, void* dev_params);
+
+/* net.load_parameters / save_parameters go through these per-tensor copies (train_yolov3.py:
+ * 293-303,323-327): host data in the REFERENCE layout; the library converts OIHW <-> device
+ * layout.  Both enqueue on `stream` and return after the copy has completed. */
+int vy_net_param_set(vy_net* net, int32_t i, const float* host_src, void* stream);
+int vy_net_param_get(vy_net* net, int32_t i, float* host_dst, void* stream);
+
+/* Shape planning.  Workspace bytes needed for inference on (batch, 3, height, width) input;
+ * height and width must be multiples of 32 (stride-32 head), at most 4096 (alloc_size =
+ * (128,128), yolo3.py:67-74). */
+size_t vy_net_workspace_bytes(const vy_net* net, int32_t batch, int32_t height, int32_t width);
+/* Bind a caller-owned device workspace of at least that size and plan for that shape.  Zeroes the
+ * workspace (asynchronously, on `stream`): the padded activation planes rely on zero borders. */
+int vy_net_bind_workspace(vy_net* net, void* dev_ws, size_t bytes, int32_t batch, int32_t height,
+                          int32_t width, void* stream);
+
+/* Number of anchors N = 3 * sum_i (H/s_i)(W/s_i) for the planned shape. */
+int32_t vy_net_num_anchors(const vy_net* net);
+
+/* net(x) outside autograd — YOLOV3T.hybrid_forward inference branch, yolo3.py:1076-1206:
+ * Darknet-53 stages -> 3 detection blocks/outputs -> decode -> box_nms -> first post_nms rows.
+ *   x        device, (batch,3,H,W) fp32 NCHW
+ *   ids      device, (batch,post_nms,1)     scores  device, (batch,post_nms,1)
+ *   bboxes   device, (batch,post_nms,4)     corner format, input-pixel units, un-clipped
+ *   keep_idx device, (batch,post_nms) int32, nullable: row index into the reference's
+ *            pre-NMS (B, N*C, 6) detection tensor for every returned row (-1 for filler).
+ * Asynchronous on `stream`. */
+int vy_net_forward_infer(vy_net* net, const float* x, float* ids, float* scores, float* bboxes,
+                         int32_t* keep_idx, void* stream);
+
+/* Debug / parity taps (asynchronous on `stream`, valid after a forward on the same stream):
+ * copy head i's prediction-conv output (yolo3.py:154 `pred`) to dst as (batch, 3*(5+C), H_i, W_i)
+ * NCHW — i = 0,1,2 for strides 32,16,8. */
+int vy_net_read_head(vy_net* net, int32_t i, float* dst_dev, void* stream);
+/* copy the activation of feature cell `name` ("stages.0.14", "yolo_blocks.1.tip", ...) to dst
+ * as NCHW; returns its channel count / height / width through the out pointers. */
+int vy_net_read_activation(vy_net* net, const char* name, float* dst_dev, int32_t* c, int32_t* h,
+                           int32_t* w, void* stream);
+
+/* Per-launch device timing of the last forward: runs one forward with HIP events recorded on
+ * `stream` around every kernel launch and returns, for launch j < *n, its name, the kernel
+ * time in ms and its algorithmic FLOPs (2*MAC; 0 for non-conv launches).  Synchronises. */
+typedef struct vy_launch_stat {
+  char name[64];
+  float ms;
+  double flops;
+  double bytes;   /* algorithmic HBM bytes (inputs read once + outputs written once) */
+} vy_launch_stat;
+int vy_net_profile_infer(vy_net* net, const float* x, float* ids, float* scores, float* bboxes,
+                         vy_launch_stat* stats, int32_t* n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VYOLO_H */

@@ -1,0 +1,137 @@
+"""-m gpu: the HIP path (through the C-ABI, via videoyolo_amd.model) against the CPU oracle on the
+same seeded inputs.  Bars (BASELINE.json north_star): NMS box indices / class ids bit-exact;
+bbox coords within 1e-4.  Because the conv kernels reproduce the oracle's fma order and
+decode uses include/vy_math.h on both sides, every comparison below is in fact exact."""
+import numpy as np
+import pytest
+
+from conftest import frames
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4  # fp32 tolerance stated by north_star for coords/scores
+
+
+def _net(classes, params, **kw):
+    import videoyolo_amd as vy
+    net = vy.yolo3_darknet53(classes, pretrained_base=False, **kw)
+    net.set_parameters(params)
+    net.collect_params().reset_ctx("cuda:0")
+    return net
+
+
+def _oracle(params, ncls=20, **kw):
+    from oracle import yolo3_oracle as O
+    return O.OracleYolo3(ncls, params, **kw)
+
+
+@pytest.mark.parametrize("batch,size", [(2, 96), (1, 64), (3, 160)])
+def test_heads_bit_exact(voc_classes, synth20, batch, size):
+    x = frames(batch, size)
+    net = _net(voc_classes, synth20)
+    net(x)
+    ref = _oracle(synth20).raw_heads(x)
+    for i in range(3):
+        got = net.read_head(i).cpu().numpy()
+        assert got.shape == ref[i].shape
+        assert np.isfinite(got).all()
+        np.testing.assert_allclose(got, ref[i], rtol=0, atol=TOL)
+        assert np.array_equal(got, ref[i]), "head %d: max |diff| %g" % (i, np.abs(got - ref[i]).max())
+
+
+@pytest.mark.parametrize("name", ["stages.0.0", "stages.0.1", "stages.0.2.body.0", "stages.0.2.body.1",
+                                  "stages.0.14.body.1", "stages.1.8.body.1", "stages.2.4.body.1",
+                                  "yolo_blocks.0.tip", "transitions.0", "yolo_blocks.1.body.0",
+                                  "yolo_blocks.2.tip"])
+def test_intermediate_cells(voc_classes, synth20, name):
+    """Layer-by-layer taps: stem, stride-2 conv, 1x1, 3x3+residual, concat-fused routes, upsample."""
+    from oracle import yolo3_oracle as O
+    x = frames(2, 64, seed=7)
+    net = _net(voc_classes, synth20)
+    net(x)
+    orc = _oracle(synth20)
+    taps = {}
+    orig = orc.cell
+
+    def cell(xx, pre, k, s):
+        y = orig(xx, pre, k, s)
+        taps[pre] = y
+        return y
+    orc.cell = cell
+    orig_block = orc.block
+
+    def block(xx, pre):
+        y = orig_block(xx, pre)
+        taps[pre + ".body.1"] = y  # the HIP path fuses the residual add into body.1's epilogue
+        return y
+    orc.block = block
+    orc.raw_heads(x)
+    got = net.read_activation(name).cpu().numpy()
+    want = taps[name]
+    if name.startswith("transitions"):
+        want = want.repeat(2, axis=-1).repeat(2, axis=-2)  # stored x2-replicated (layers.py:20)
+    assert got.shape == want.shape
+    assert np.array_equal(got, want), "max |diff| %g" % np.abs(got - want).max()
+
+
+@pytest.mark.parametrize("batch,size,obj_bias", [(2, 96, 0.0), (2, 128, -3.0), (1, 416, 0.0)])
+def test_detections_match_oracle(voc_classes, batch, size, obj_bias):
+    from videoyolo_amd import init
+    from oracle import yolo3_oracle as O
+    params = init.synthetic_params(O.param_shapes(20), seed=233, obj_bias=obj_bias)
+    x = frames(batch, size)
+    net = _net(voc_classes, params)
+    net.set_nms(0.45, 400, 100)
+    ids, scores, bboxes, keep = [t.cpu().numpy() for t in net(x, return_index=True)]
+    r_ids, r_scores, r_bboxes, r_keep = _oracle(params)(x)
+    assert ids.shape == (batch, 100, 1) and scores.shape == (batch, 100, 1) and bboxes.shape == (batch, 100, 4)
+    assert np.array_equal(keep, r_keep), "NMS kept-row indices differ"
+    assert np.array_equal(ids, r_ids), "class ids differ"
+    np.testing.assert_allclose(scores, r_scores, rtol=0, atol=TOL)
+    fin = np.isfinite(r_bboxes)
+    assert np.array_equal(np.isfinite(bboxes), fin)
+    np.testing.assert_allclose(bboxes[fin], r_bboxes[fin], rtol=0, atol=TOL)
+    assert (ids >= 0).sum() > 0
+
+
+def test_nms_settings_and_30_classes():
+    """set_nms(…) variants + the ImageNet-VID class count (config 4: 30 classes)."""
+    from videoyolo_amd import init
+    from oracle import yolo3_oracle as O
+    classes = ["c%d" % i for i in range(30)]
+    params = init.synthetic_params(O.param_shapes(30), seed=5)
+    x = frames(2, 96, seed=3)
+    net = _net(classes, params)
+    for thr, topk, post in [(0.45, 400, 100), (0.3, 50, 20), (0.6, 1000, 300), (0.45, 7, 100)]:
+        net.set_nms(thr, topk, post)
+        ids, scores, bboxes, keep = [t.cpu().numpy() for t in net(x, return_index=True)]
+        r = _oracle(params, 30, nms_thresh=thr, nms_topk=topk, post_nms=post)(x)
+        assert np.array_equal(keep, r[3]), (thr, topk, post)
+        assert np.array_equal(ids, r[0])
+        np.testing.assert_allclose(scores, r[1], rtol=0, atol=TOL)
+
+
+def test_ties_and_empty():
+    """Degenerate inputs: all-zero weights give every candidate the SAME score (0.25): the order
+    must fall back to the reference row index; a very negative objectness bias leaves no valid
+    candidate: all rows -1."""
+    from videoyolo_amd import init
+    from oracle import yolo3_oracle as O
+    classes = ["a", "b", "c"]
+    table = O.param_shapes(3)
+    params = init.uniform_params(table, seed=0)
+    for k in params:
+        if k.endswith("weight"):
+            params[k] = np.zeros_like(params[k])
+    x = frames(1, 64)
+    net = _net(classes, params)
+    ids, scores, bboxes, keep = [t.cpu().numpy() for t in net(x, return_index=True)]
+    r = _oracle(params, 3)(x)
+    assert np.array_equal(keep, r[3])
+    assert np.array_equal(ids, r[0])
+    assert np.array_equal(scores, r[1])
+    for i in range(3):
+        params["yolo_outputs.%d.prediction.bias" % i].reshape(3, -1)[:, 4] = -30.0
+    net = _net(classes, params)
+    ids, scores, bboxes, keep = [t.cpu().numpy() for t in net(x, return_index=True)]
+    assert (ids == -1).all() and (scores == -1).all() and (bboxes == -1).all() and (keep == -1).all()

@@ -1,0 +1,416 @@
+// detect.hip — the detection tail: YOLOOutputV3 decode + contrib.box_nms + top post_nms rows.
+//
+// Replaces, without ever materialising the (B, N*C, 6) detection tensor the reference builds:
+//   models/definitions/yolo/yolo3.py:158-197   (reshape/transpose, sigmoid/exp decode, x C tile,
+//                                               class-major (B, C*HW*A, 6) layout)
+//   models/definitions/yolo/yolo3.py:1195      (concat of the three scales, stride 32,16,8)
+//   models/definitions/yolo/yolo3.py:1198-1206 (box_nms(valid 0.01, topk, per class) + slice)
+//
+// Candidate r of image b (the row index of the reference's detection tensor) is
+//   r = cand_base[scale] + c*(H*W*A) + (y*W + x)*A + a
+// and its sort key is (score, -r): box_nms orders by score descending and this implementation
+// breaks score ties by ascending r (a stable sort of the reference's tensor).
+//
+// Pipeline per batch (all images in parallel; every pass re-decodes from the 3 head planes,
+// 1.1-2.3 MB per image, instead of storing 5-16 MB of candidates per image):
+//   1. radix select of the k-th largest key, k = min(topk, #valid): pass 0 buckets the score
+//      linearly (1024 buckets, spreads LDS-atomic contention), passes 1-3 refine the score bits
+//      10 at a time inside the chosen bucket, passes 4-6 refine the inverted row index among
+//      candidates that tie with the k-th score.  A pass is skipped once the threshold is exact.
+//   2. collect the k candidates at or above the threshold, decoding their boxes.
+//   3. one workgroup per image: bitonic sort by key, greedy per-class IoU suppression,
+//      compaction, write the first post_nms rows (-1 filler).
+// HBM-bound integer/byte work: coalesced channel-contiguous reads, LDS histograms, no MFMA.
+#include "kernels.h"
+#include "../../include/vy_math.h"
+
+namespace {
+
+constexpr int kBins = 1024;
+constexpr int kItemsPerThread = 4;
+constexpr int kHistThreads = 256;
+constexpr int kIdxBits = 30;
+
+struct SelState {
+  uint32_t Tb;            // selected linear bucket
+  uint32_t Ts, smask;     // determined score bits / their mask
+  uint32_t Ti, imask;     // determined inverted-index bits / their mask
+  int32_t k_rem;          // rank still to resolve inside the current prefix
+  int32_t k_eff;          // min(topk, nvalid)
+  int32_t done;           // threshold exact: later passes are no-ops
+  int32_t count;          // collect counter
+  int32_t pad[7];
+};
+
+struct Entry {
+  uint32_t sbits, inv;
+  float x1, y1, x2, y2;
+  float cls;
+  uint32_t pad;
+};
+
+struct Scratch {
+  // [B] SelState | [B][kBins] hist | [B][VY_NMS_MAX_TOPK] Entry
+  SelState* st;
+  uint32_t* hist;
+  Entry* ent;
+};
+
+__host__ __device__ inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+__host__ __device__ inline Scratch carve(void* base, int B) {
+  unsigned char* p = (unsigned char*)base;
+  Scratch s;
+  s.st = (SelState*)p;
+  p += align256(sizeof(SelState) * (size_t)B);
+  s.hist = (uint32_t*)p;
+  p += align256(sizeof(uint32_t) * (size_t)B * kBins);
+  s.ent = (Entry*)p;
+  return s;
+}
+
+__device__ __forceinline__ uint32_t score_bucket(float s) {
+  int b = (int)(s * 1024.0f);
+  return (uint32_t)(b > 1023 ? 1023 : b);
+}
+
+// Locate item `it` (anchor-level work item of one image) -> scale, cell, anchor, and a pointer to
+// its 5+C raw predictions.  Items are ordered scale -> cell -> anchor like the candidate index.
+struct Item {
+  const float* p;   // raw predictions of this anchor: [x, y, w, h, obj, cls...]
+  int scale, x, y, a;
+  int cand0;        // candidate index of class 0 for this (cell, anchor)
+  int cstride;      // candidate index stride between classes = H*W*A
+};
+
+__device__ __forceinline__ bool locate(const DetArgs& d, int b, int it, Item& o) {
+  int s = 0;
+#pragma unroll
+  for (; s < 3; ++s) {
+    const int n = d.head[s].H * d.head[s].W * 3;
+    if (it < n) break;
+    it -= n;
+  }
+  if (s == 3) return false;
+  const HeadView& hv = d.head[s];
+  const int a = it % 3;
+  const int cell = it / 3;
+  const int x = cell % hv.W, y = cell / hv.W;
+  o.scale = s;
+  o.x = x;
+  o.y = y;
+  o.a = a;
+  o.cstride = hv.H * hv.W * 3;
+  o.cand0 = hv.cand_base + it;
+  o.p = hv.pred + ((long long)(b * (hv.H + 2) + y + 1) * (hv.W + 2) + x + 1) * hv.cs + hv.co + a * (5 + d.C);
+  return true;
+}
+
+__device__ __forceinline__ bool prefix_match(const SelState& st, int pass, uint32_t bucket, uint32_t sbits,
+                                             uint32_t inv) {
+  if (pass == 0) return true;
+  return bucket == st.Tb && (sbits & st.smask) == st.Ts && (inv & st.imask) == st.Ti;
+}
+
+__device__ __forceinline__ uint32_t pass_digit(int pass, uint32_t bucket, uint32_t sbits, uint32_t inv) {
+  switch (pass) {
+    case 0: return bucket;
+    case 1: return (sbits >> 20) & 1023u;
+    case 2: return (sbits >> 10) & 1023u;
+    case 3: return sbits & 1023u;
+    case 4: return (inv >> 20) & 1023u;
+    case 5: return (inv >> 10) & 1023u;
+    default: return inv & 1023u;
+  }
+}
+
+__global__ __launch_bounds__(kHistThreads) void hist_kernel(const DetArgs d, void* scratch, int pass, int n_items) {
+  const int b = blockIdx.y;
+  Scratch sc = carve(scratch, d.B);
+  const SelState st = sc.st[b];
+  if (st.done) return;
+  __shared__ uint32_t lh[kBins];
+  for (int i = threadIdx.x; i < kBins; i += kHistThreads) lh[i] = 0;
+  __syncthreads();
+  const int base = blockIdx.x * (kHistThreads * kItemsPerThread);
+#pragma unroll 1
+  for (int q = 0; q < kItemsPerThread; ++q) {
+    const int it = base + q * kHistThreads + threadIdx.x;
+    Item im;
+    if (it >= n_items || !locate(d, b, it, im)) continue;
+    const float conf = vy_sigmoidf(im.p[4]);
+    for (int c = 0; c < d.C; ++c) {
+      const float s = vy_sigmoidf(im.p[5 + c]) * conf;
+      if (!(s > d.valid_thresh)) continue;
+      const uint32_t sbits = vy_f32_to_bits(s);
+      const uint32_t inv = ((1u << kIdxBits) - 1u) - (uint32_t)(im.cand0 + c * im.cstride);
+      const uint32_t bucket = score_bucket(s);
+      if (!prefix_match(st, pass, bucket, sbits, inv)) continue;
+      atomicAdd(&lh[pass_digit(pass, bucket, sbits, inv)], 1u);
+    }
+  }
+  __syncthreads();
+  uint32_t* gh = sc.hist + (size_t)b * kBins;
+  for (int i = threadIdx.x; i < kBins; i += kHistThreads) {
+    const uint32_t v = lh[i];
+    if (v) atomicAdd(&gh[i], v);
+  }
+}
+
+// one block (kBins threads) per image: find the bin holding rank k_rem (counted from the top),
+// fix that digit, zero the histogram for the next pass.
+__global__ __launch_bounds__(kBins) void select_kernel(const DetArgs d, void* scratch, int pass) {
+  const int b = blockIdx.x;
+  Scratch sc = carve(scratch, d.B);
+  SelState* st = sc.st + b;
+  if (st->done) return;
+  uint32_t* gh = sc.hist + (size_t)b * kBins;
+  __shared__ uint32_t suf[kBins];  // suffix sums: suf[i] = sum_{j >= i} hist[j]
+  const int t = threadIdx.x;
+  const uint32_t mine = gh[t];
+  gh[t] = 0;
+  suf[t] = mine;
+  __syncthreads();
+  for (int off = 1; off < kBins; off <<= 1) {
+    const uint32_t add = (t + off < kBins) ? suf[t + off] : 0u;
+    __syncthreads();
+    suf[t] += add;
+    __syncthreads();
+  }
+  __shared__ int32_t k_rem_s;
+  if (t == 0) {
+    if (pass == 0) {
+      const int nvalid = (int)suf[0];
+      const int k_eff = nvalid < d.topk ? nvalid : d.topk;
+      st->k_eff = k_eff;
+      st->k_rem = k_eff;
+      if (k_eff == 0) st->done = 1;
+    }
+    k_rem_s = st->k_rem;
+  }
+  __syncthreads();
+  const int k_rem = k_rem_s;
+  if (k_rem <= 0) return;
+  const uint32_t above = (t + 1 < kBins) ? suf[t + 1] : 0u;  // candidates in strictly higher bins
+  if (above < (uint32_t)k_rem && (uint32_t)k_rem <= above + mine) {
+    // this is the bin
+    const int rem = k_rem - (int)above;
+    st->k_rem = rem;
+    const uint32_t dgt = (uint32_t)t;
+    switch (pass) {
+      case 0: st->Tb = dgt; break;
+      case 1: st->Ts |= dgt << 20; st->smask |= 1023u << 20; break;
+      case 2: st->Ts |= dgt << 10; st->smask |= 1023u << 10; break;
+      case 3: st->Ts |= dgt; st->smask |= 1023u; break;
+      case 4: st->Ti |= dgt << 20; st->imask |= 1023u << 20; break;
+      case 5: st->Ti |= dgt << 10; st->imask |= 1023u << 10; break;
+      default: st->Ti |= dgt; st->imask |= 1023u; break;
+    }
+    // every candidate of this bin is wanted: the threshold "prefix, rest zero" is already exact
+    if ((uint32_t)rem == mine || pass == 6) st->done = 1;
+  }
+}
+
+__device__ __forceinline__ void decode_box(const DetArgs& d, const Item& im, float& x1, float& y1, float& x2,
+                                           float& y2) {
+  const HeadView& hv = d.head[im.scale];
+  // yolo3.py:172-177, same operation order (no contraction)
+  const float cx = (vy_sigmoidf(im.p[0]) + (float)im.x) * hv.stride;
+  const float cy = (vy_sigmoidf(im.p[1]) + (float)im.y) * hv.stride;
+  const float w = vy_expf(im.p[2]) * hv.aw[im.a];
+  const float h = vy_expf(im.p[3]) * hv.ah[im.a];
+  const float hw = w / 2.0f, hh = h / 2.0f;
+  x1 = cx - hw;
+  y1 = cy - hh;
+  x2 = cx + hw;
+  y2 = cy + hh;
+}
+
+__global__ __launch_bounds__(kHistThreads) void collect_kernel(const DetArgs d, void* scratch, int n_items) {
+  const int b = blockIdx.y;
+  Scratch sc = carve(scratch, d.B);
+  SelState* stp = sc.st + b;
+  const SelState st = *stp;
+  if (st.k_eff <= 0) return;
+  Entry* ent = sc.ent + (size_t)b * VY_NMS_MAX_TOPK;
+  const int base = blockIdx.x * (kHistThreads * kItemsPerThread);
+#pragma unroll 1
+  for (int q = 0; q < kItemsPerThread; ++q) {
+    const int it = base + q * kHistThreads + threadIdx.x;
+    Item im;
+    if (it >= n_items || !locate(d, b, it, im)) continue;
+    const float conf = vy_sigmoidf(im.p[4]);
+    bool have_box = false;
+    float x1 = 0, y1 = 0, x2 = 0, y2 = 0;
+    for (int c = 0; c < d.C; ++c) {
+      const float s = vy_sigmoidf(im.p[5 + c]) * conf;
+      if (!(s > d.valid_thresh)) continue;
+      const uint32_t sbits = vy_f32_to_bits(s);
+      const uint32_t inv = ((1u << kIdxBits) - 1u) - (uint32_t)(im.cand0 + c * im.cstride);
+      const uint32_t bucket = score_bucket(s);
+      const bool take = bucket > st.Tb ||
+                        (bucket == st.Tb && (sbits > st.Ts || (sbits == st.Ts && inv >= st.Ti)));
+      if (!take) continue;
+      if (!have_box) {
+        decode_box(d, im, x1, y1, x2, y2);
+        have_box = true;
+      }
+      const int slot = atomicAdd(&stp->count, 1);
+      if (slot < VY_NMS_MAX_TOPK) {
+        Entry e;
+        e.sbits = sbits;
+        e.inv = inv;
+        e.x1 = x1;
+        e.y1 = y1;
+        e.x2 = x2;
+        e.y2 = y2;
+        e.cls = (float)c;
+        e.pad = 0;
+        ent[slot] = e;
+      }
+    }
+  }
+}
+
+constexpr int kNmsThreads = 512;
+
+// one workgroup per image: sort the <= topk collected entries by key (descending), greedy
+// per-class suppression in that order, compact, write the first `rows` rows.
+__global__ __launch_bounds__(kNmsThreads) void sort_nms_kernel(const DetArgs d, void* scratch, int rows, float* ids,
+                                                               float* scores, float* bboxes, int32_t* keep_idx) {
+  const int b = blockIdx.x;
+  Scratch sc = carve(scratch, d.B);
+  const SelState st = sc.st[b];
+  const Entry* ent = sc.ent + (size_t)b * VY_NMS_MAX_TOPK;
+  __shared__ unsigned long long key[VY_NMS_MAX_TOPK];
+  __shared__ uint16_t perm[VY_NMS_MAX_TOPK];
+  __shared__ float bx1[VY_NMS_MAX_TOPK], by1[VY_NMS_MAX_TOPK], bx2[VY_NMS_MAX_TOPK], by2[VY_NMS_MAX_TOPK];
+  __shared__ float bcls[VY_NMS_MAX_TOPK];
+  __shared__ uint8_t alive[VY_NMS_MAX_TOPK];
+  __shared__ int pos[VY_NMS_MAX_TOPK];
+  const int t = threadIdx.x;
+  int k = st.k_eff;
+  if (k > VY_NMS_MAX_TOPK) k = VY_NMS_MAX_TOPK;
+  int kp = 1;
+  while (kp < k) kp <<= 1;
+  for (int i = t; i < kp; i += kNmsThreads) {
+    if (i < k) {
+      key[i] = ((unsigned long long)ent[i].sbits << 32) | ent[i].inv;
+      perm[i] = (uint16_t)i;
+    } else {
+      key[i] = 0ull;  // sorts last (valid keys have sbits > 0)
+      perm[i] = 0;
+    }
+  }
+  __syncthreads();
+  // bitonic sort, descending
+  for (int size = 2; size <= kp; size <<= 1) {
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      for (int i = t; i < (kp >> 1); i += kNmsThreads) {
+        const int lo = ((i / stride) * (stride << 1)) + (i % stride);
+        const int hi = lo + stride;
+        const bool desc = ((lo & size) == 0);
+        const unsigned long long a = key[lo], c = key[hi];
+        if ((a < c) == desc) {
+          key[lo] = c;
+          key[hi] = a;
+          const uint16_t pa = perm[lo];
+          perm[lo] = perm[hi];
+          perm[hi] = pa;
+        }
+      }
+      __syncthreads();
+    }
+  }
+  for (int i = t; i < k; i += kNmsThreads) {
+    const Entry e = ent[perm[i]];
+    bx1[i] = e.x1;
+    by1[i] = e.y1;
+    bx2[i] = e.x2;
+    by2[i] = e.y2;
+    bcls[i] = e.cls;
+    alive[i] = 1;
+  }
+  __syncthreads();
+  if (d.do_nms) {
+    for (int i = 0; i < k; ++i) {
+      if (!alive[i]) continue;  // uniform: alive[] is only written before the barrier below
+      const float ax1 = bx1[i], ay1 = by1[i], ax2 = bx2[i], ay2 = by2[i], ac = bcls[i];
+      for (int j = i + 1 + t; j < k; j += kNmsThreads) {
+        if (alive[j] && bcls[j] == ac) {
+          const float iou = vy_box_iou(ax1, ay1, ax2, ay2, bx1[j], by1[j], bx2[j], by2[j]);
+          if (iou > d.nms_thresh) alive[j] = 0;
+        }
+      }
+      __syncthreads();
+    }
+  }
+  // compaction: exclusive scan of alive[] (k <= 1024, two elements per thread)
+  for (int i = t; i < VY_NMS_MAX_TOPK; i += kNmsThreads) pos[i] = (i < k && alive[i]) ? 1 : 0;
+  __syncthreads();
+  for (int off = 1; off < VY_NMS_MAX_TOPK; off <<= 1) {
+    int v0 = 0, v1 = 0;
+    const int i0 = t, i1 = t + kNmsThreads;
+    if (i0 >= off) v0 = pos[i0 - off];
+    if (i1 >= off) v1 = pos[i1 - off];
+    __syncthreads();
+    pos[i0] += v0;
+    pos[i1] += v1;
+    __syncthreads();
+  }
+  const int n_keep = pos[VY_NMS_MAX_TOPK - 1];
+  for (int i = t; i < k; i += kNmsThreads) {
+    if (!alive[i]) continue;
+    const int r = pos[i] - 1;
+    if (r >= rows) continue;
+    const size_t o = (size_t)b * rows + r;
+    ids[o] = bcls[i];
+    scores[o] = vy_bits_to_f32((uint32_t)(key[i] >> 32));
+    bboxes[o * 4 + 0] = bx1[i];
+    bboxes[o * 4 + 1] = by1[i];
+    bboxes[o * 4 + 2] = bx2[i];
+    bboxes[o * 4 + 3] = by2[i];
+    if (keep_idx) keep_idx[o] = (int32_t)(((1u << kIdxBits) - 1u) - (uint32_t)(key[i] & 0xffffffffull));
+  }
+  for (int r = n_keep + t; r < rows; r += kNmsThreads) {
+    const size_t o = (size_t)b * rows + r;
+    ids[o] = -1.0f;
+    scores[o] = -1.0f;
+    bboxes[o * 4 + 0] = -1.0f;
+    bboxes[o * 4 + 1] = -1.0f;
+    bboxes[o * 4 + 2] = -1.0f;
+    bboxes[o * 4 + 3] = -1.0f;
+    if (keep_idx) keep_idx[o] = -1;
+  }
+}
+
+}  // namespace
+
+size_t vy_det_scratch_bytes(int B) {
+  return align256(sizeof(SelState) * (size_t)B) + align256(sizeof(uint32_t) * (size_t)B * kBins) +
+         align256(sizeof(Entry) * (size_t)B * VY_NMS_MAX_TOPK);
+}
+
+hipError_t vy_launch_detect(const DetArgs& a, void* scratch, float* ids, float* scores, float* bboxes,
+                            int32_t* keep_idx, hipStream_t s) {
+  if (a.topk <= 0 || a.topk > VY_NMS_MAX_TOPK || a.n_cand >= (1 << kIdxBits)) return hipErrorInvalidValue;
+  const int rows = a.post_nms > 0 ? a.post_nms : a.topk;
+  // state + histogram region back to zero (entries need no clearing)
+  hipError_t e = hipMemsetAsync(scratch, 0,
+                                align256(sizeof(SelState) * (size_t)a.B) +
+                                    align256(sizeof(uint32_t) * (size_t)a.B * kBins),
+                                s);
+  if (e != hipSuccess) return e;
+  int n_items = 0;
+  for (int i = 0; i < 3; ++i) n_items += a.head[i].H * a.head[i].W * 3;
+  const int per_block = kHistThreads * kItemsPerThread;
+  dim3 grid((n_items + per_block - 1) / per_block, a.B);
+  for (int pass = 0; pass < 7; ++pass) {
+    hipLaunchKernelGGL(hist_kernel, grid, dim3(kHistThreads), 0, s, a, scratch, pass, n_items);
+    hipLaunchKernelGGL(select_kernel, dim3(a.B), dim3(kBins), 0, s, a, scratch, pass);
+  }
+  hipLaunchKernelGGL(collect_kernel, grid, dim3(kHistThreads), 0, s, a, scratch, n_items);
+  hipLaunchKernelGGL(sort_nms_kernel, dim3(a.B), dim3(kNmsThreads), 0, s, a, scratch, rows, ids, scores, bboxes,
+                     keep_idx);
+  return hipGetLastError();
+}

@@ -1,0 +1,504 @@
+"""The model object: ``yolo3_darknet53(classes, ...)`` with the surface the reference's drivers use.
+
+Host-side mirror (Python, like the reference) of the Gluon HybridBlock that
+``models/definitions/yolo/wrappers.py:9-110`` returns (``YOLOV3T`` at k=1,
+``models/definitions/yolo/yolo3.py:915-1302``), over the C-ABI of ``include/vyolo.h``.
+All tensor work happens in libvyolo.so (hand-written HIP for gfx950); torch is used only for device
+memory, streams and (in ``videoyolo_amd.parallel``) torch.distributed.
+
+Call sites this surface serves (paths relative to /root/reference):
+  construction      train_yolov3.py:350-360,384-392   detect_yolo3.py:873-880
+  initialize        train_yolov3.py:428               detect_yolo3.py:885
+  load/save params  train_yolov3.py:293-303,323-327   detect_yolo3.py:890
+  collect_params    train_yolov3.py:494-497,527       detect_yolo3.py:199   wrappers.py:55-57
+  hybridize         train_yolov3.py:441,586
+  set_nms           train_yolov3.py:438               detect_yolo3.py:200
+  reset_class       train_yolov3.py:728-729
+  __call__          detect_yolo3.py:222 (inference)   train_yolov3.py:625 (recording)
+"""
+import copy
+import ctypes
+import re
+import warnings
+from collections import OrderedDict
+
+import numpy as np
+
+from . import _lib, autograd, init as _init
+
+_KINDS = ["weight", "gamma", "beta", "running_mean", "running_var", "bias"]
+
+
+class BatchNorm:
+    """Marker for ``norm_layer=BatchNorm`` (mxnet.gluon.nn.BatchNorm)."""
+
+
+class SyncBatchNorm:
+    """Marker for ``norm_layer=gluon.contrib.nn.SyncBatchNorm`` (train_yolov3.py:352)."""
+
+
+class Parameter:
+    """One row of ``collect_params()``: gluon.Parameter's attributes the drivers touch."""
+
+    def __init__(self, net, index, info):
+        self._net = net
+        self.index = index
+        self.name = info.name.decode()
+        self.kind = _KINDS[info.kind]
+        self.shape = tuple(info.shape[i] for i in range(info.ndim))
+        self.size = int(info.size)
+        self.offset = int(info.offset)
+        self.trainable = bool(info.trainable)
+        self.backbone = bool(info.backbone)
+        self.grad_req = "write" if self.trainable else "null"
+        self.wd_mult = 1.0
+        self.lr_mult = 1.0
+
+    def data(self, ctx=None):
+        """Value in the reference layout (OIHW for conv weights), as numpy."""
+        return self._net._get_param(self.index)
+
+    def set_data(self, value):
+        value = np.ascontiguousarray(value, dtype=np.float32)
+        if value.shape != self.shape:
+            raise ValueError("%s: shape %s does not match %s" % (self.name, value.shape, self.shape))
+        self._net._set_param(self.index, value)
+
+    def __repr__(self):
+        return "Parameter %s (shape=%s, dtype=float32)" % (self.name, self.shape)
+
+
+class ParameterDict(OrderedDict):
+    def __init__(self, net, items=()):
+        super().__init__(items)
+        self._net = net
+
+    def reset_ctx(self, ctx):
+        self._net.reset_ctx(ctx)
+
+    def setattr(self, name, value):
+        for p in self.values():
+            setattr(p, name, value)
+
+    def zero_grad(self):
+        pass
+
+
+class _TargetGeneratorState:
+    """Holder for ``net._target_generator._label_smooth`` (train_yolov3.py:500)."""
+
+    def __init__(self, num_class, ignore_iou_thresh):
+        self._num_class = num_class
+        self._ignore_iou_thresh = ignore_iou_thresh
+        self._label_smooth = False
+
+
+def _torch():
+    import torch
+    return torch
+
+
+class YOLOV3(object):
+    """yolo3_darknet53 detector bound to one device / stream."""
+
+    def __init__(self, classes, nms_thresh=0.45, nms_topk=400, post_nms=100, pos_iou_thresh=1.0,
+                 ignore_iou_thresh=0.7, norm_layer=BatchNorm, norm_kwargs=None, alloc_size=(128, 128)):
+        if pos_iou_thresh < 1:
+            raise NotImplementedError(
+                "pos_iou_thresh({}) < 1.0 is not implemented!".format(pos_iou_thresh))  # yolo3.py:992
+        self._classes = list(classes)
+        self._lib = _lib.load()
+        h = ctypes.c_void_p()
+        _lib.check(self._lib.vy_net_create(len(self._classes), ctypes.byref(h)))
+        self._h = h
+        self.nms_thresh, self.nms_topk, self.post_nms = nms_thresh, nms_topk, post_nms
+        self._ignore_iou_thresh = ignore_iou_thresh
+        self._pos_iou_thresh = pos_iou_thresh
+        self._norm_layer, self._norm_kwargs = norm_layer, norm_kwargs
+        self._alloc_size = alloc_size
+        self._target_generator = _TargetGeneratorState(len(self._classes), ignore_iou_thresh)
+        self._params = ParameterDict(self)
+        n = self._lib.vy_net_num_params(self._h)
+        for i in range(n):
+            info = _lib.ParamInfo()
+            _lib.check(self._lib.vy_net_param_info(self._h, i, ctypes.byref(info)))
+            p = Parameter(self, i, info)
+            self._params[p.name] = p
+        self._host = {}          # name -> numpy (reference layout) while not on a device
+        self._dev_params = None  # torch uint8 tensor holding the device parameter buffer
+        self._ws = None          # torch uint8 workspace
+        self._plan = None        # (B, H, W) the workspace is planned for
+        self._device = None
+        self._hybrid = False
+        _lib.check(self._lib.vy_net_set_nms(self._h, nms_thresh, nms_topk, post_nms))
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                self._lib.vy_net_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ properties
+    @property
+    def classes(self):
+        """yolo3.py:1066-1074"""
+        return self._classes
+
+    @property
+    def num_class(self):
+        # The reference reads self._num_class, which is never assigned (yolo3.py:1057-1064), so
+        # the property raises AttributeError there; here it returns the obvious value.
+        return len(self._classes)
+
+    def param_table(self):
+        return [(p.name, p.shape) for p in self._params.values()]
+
+    # ------------------------------------------------------------------ parameters
+    def collect_params(self, select=None):
+        if select is None:
+            return self._params
+        pat = re.compile(select)
+        return ParameterDict(self, [(k, v) for k, v in self._params.items() if pat.match(k)])
+
+    def initialize(self, init=None, ctx=None, force_reinit=False, seed=None, **kwargs):
+        """``net.initialize()``: 'uniform' (gluon default) or 'synthetic' (videoyolo_amd.init)."""
+        if self._host and not force_reinit and self._all_set():
+            warnings.warn("parameters already initialized; use force_reinit=True")
+        else:
+            table = self.param_table()
+            if init in (None, "uniform"):
+                vals = _init.uniform_params(table, seed)
+            elif init == "synthetic":
+                vals = _init.synthetic_params(table, 233 if seed is None else seed, **kwargs)
+            elif callable(init):
+                vals = init(table)
+            else:
+                raise ValueError("unknown initializer %r" % (init,))
+            for k, v in vals.items():
+                self._params[k].set_data(v)
+        if ctx is not None:
+            self.reset_ctx(ctx)
+
+    def _all_set(self):
+        return self._dev_params is not None or len(self._host) == len(self._params)
+
+    def _stream(self):
+        torch = _torch()
+        return ctypes.c_void_p(torch.cuda.current_stream(self._device).cuda_stream)
+
+    def _get_param(self, i):
+        p = list(self._params.values())[i] if not isinstance(i, Parameter) else i
+        if self._dev_params is None:
+            if p.name not in self._host:
+                raise RuntimeError("Parameter %s has not been initialized" % p.name)
+            return self._host[p.name].copy()
+        out = np.empty(p.shape, np.float32)
+        torch = _torch()
+        with torch.cuda.device(self._device):
+            _lib.check(self._lib.vy_net_param_get(self._h, p.index, out.ctypes.data_as(ctypes.c_void_p),
+                                                  self._stream()))
+        return out
+
+    def _set_param(self, i, value):
+        p = list(self._params.values())[i]
+        if self._dev_params is None:
+            self._host[p.name] = value.copy()
+            return
+        torch = _torch()
+        with torch.cuda.device(self._device):
+            _lib.check(self._lib.vy_net_param_set(self._h, p.index, value.ctypes.data_as(ctypes.c_void_p),
+                                                  self._stream()))
+
+    def reset_ctx(self, ctx):
+        """Move the parameters to a device (``net.collect_params().reset_ctx(ctx)``).  ctx: a
+        torch.device / 'cuda:N' / int, or a one-element list of those (one net per device)."""
+        torch = _torch()
+        if isinstance(ctx, (list, tuple)):
+            if len(ctx) != 1:
+                raise ValueError("one YOLOV3 object drives one device; use videoyolo_amd.parallel for N devices")
+            ctx = ctx[0]
+        dev = torch.device("cuda", ctx) if isinstance(ctx, int) else torch.device(ctx)
+        if dev.type != "cuda":
+            raise RuntimeError("videoyolo_amd runs on an MI355X (cuda/hip device); there is no CPU path")
+        if self._dev_params is not None and dev == self._device:
+            return
+        vals = {p.name: self._get_param(p.index) for p in self._params.values()} if self._all_set() else None
+        if vals is None:
+            raise RuntimeError("initialize() or load_parameters() before reset_ctx()")
+        self._device = dev
+        nbytes = self._lib.vy_net_param_bytes(self._h)
+        self._dev_params = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
+        _lib.check(self._lib.vy_net_bind_params(self._h, ctypes.c_void_p(self._dev_params.data_ptr())))
+        self._host = {}
+        self._ws, self._plan = None, None
+        for i, p in enumerate(self._params.values()):
+            self._set_param(i, vals[p.name])
+
+    def save_parameters(self, filename):
+        """Container: numpy .npz keyed by gluon structural names, reference layouts.  (The
+        reference writes mxnet's NDArray-dict format, which cannot be produced or validated
+        offline; see INTEGRATION.md.)"""
+        arrays = {p.name: self._get_param(p.index) for p in self._params.values()}
+        with open(filename, "wb") as f:
+            np.savez(f, **arrays)
+
+    def load_parameters(self, filename, ctx=None, allow_missing=False, ignore_extra=False):
+        with np.load(filename) as z:
+            loaded = {k: z[k] for k in z.files}
+        self.set_parameters(loaded, allow_missing=allow_missing, ignore_extra=ignore_extra)
+        if ctx is not None:
+            self.reset_ctx(ctx)
+
+    def set_parameters(self, arrays, allow_missing=False, ignore_extra=False):
+        """Load a {structural name: array} dict (reference layouts)."""
+        missing = [k for k in self._params if k not in arrays]
+        extra = [k for k in arrays if k not in self._params]
+        if missing and not allow_missing:
+            raise AssertionError("Parameter '%s' is missing in the file" % missing[0])
+        if extra and not ignore_extra:
+            raise AssertionError("Parameter '%s' loaded from the file is not present in the net" % extra[0])
+        for k, v in arrays.items():
+            if k in self._params:
+                self._params[k].set_data(np.asarray(v, np.float32))
+
+    # ------------------------------------------------------------------ configuration
+    def hybridize(self, active=True, **kwargs):
+        self._hybrid = bool(active)
+
+    def set_nms(self, nms_thresh=0.45, nms_topk=400, post_nms=100):
+        """yolo3.py:1208-1228"""
+        self.nms_thresh, self.nms_topk, self.post_nms = nms_thresh, nms_topk, post_nms
+        _lib.check(self._lib.vy_net_set_nms(self._h, nms_thresh, nms_topk, post_nms))
+
+    def reset_class(self, classes, reuse_weights=None):
+        """yolo3.py:1230-1302 + YOLOOutputV3.reset_class yolo3.py:76-129: new class list, fresh
+        prediction convs, optionally re-using rows of the old predictors."""
+        old_classes = self._classes
+        classes = list(classes)
+        if isinstance(reuse_weights, (dict, list)):
+            if isinstance(reuse_weights, dict):
+                new_keys, new_vals = [], []
+                for k, v in reuse_weights.items():
+                    if isinstance(v, str):
+                        try:
+                            new_vals.append(old_classes.index(v))
+                        except ValueError:
+                            raise ValueError("{} not found in old class names {}".format(v, old_classes))
+                    else:
+                        if v < 0 or v >= len(old_classes):
+                            raise ValueError("Index {} out of bounds for old class names".format(v))
+                        new_vals.append(v)
+                    if isinstance(k, str):
+                        try:
+                            new_keys.append(classes.index(k))
+                        except ValueError:
+                            raise ValueError("{} not found in new class names {}".format(k, classes))
+                    else:
+                        if k < 0 or k >= len(classes):
+                            raise ValueError("Index {} out of bounds for new class names".format(k))
+                        new_keys.append(k)
+                reuse_weights = dict(zip(new_keys, new_vals))
+            else:
+                new_map = {}
+                for x in reuse_weights:
+                    try:
+                        new_map[classes.index(x)] = old_classes.index(x)
+                    except ValueError:
+                        warnings.warn("{} not found in old: {} or new class names: {}".format(
+                            x, old_classes, classes))
+                reuse_weights = new_map
+        old_vals = {p.name: self._get_param(p.index) for p in self._params.values()}
+        device = self._device
+        fresh = YOLOV3(classes, self.nms_thresh, self.nms_topk, self.post_nms, self._pos_iou_thresh,
+                       self._ignore_iou_thresh, self._norm_layer, self._norm_kwargs, self._alloc_size)
+        new_vals = _init.uniform_params(fresh.param_table())  # prediction.initialize(), yolo3.py:110
+        old_np, new_np = 5 + len(old_classes), 5 + len(classes)
+        for name in new_vals:
+            if "prediction" not in name:
+                new_vals[name] = old_vals[name]
+            elif reuse_weights:
+                od, nd = old_vals[name], new_vals[name]
+                for k, v in reuse_weights.items():
+                    if k >= len(classes) or v >= len(old_classes):
+                        warnings.warn("reuse mapping {}/{} -> {}/{} out of range".format(
+                            k, len(classes), v, len(old_classes)))
+                        continue
+                    for a in range(3):
+                        nd[5 + k + a * new_np] = od[5 + v + a * old_np]
+                        nd[a * new_np:5 + a * new_np] = od[a * old_np:5 + a * old_np]
+        # adopt the fresh object's state
+        self._lib.vy_net_destroy(self._h)
+        self.__dict__.update({k: v for k, v in fresh.__dict__.items()
+                              if k in ("_h", "_params", "_classes", "_target_generator")})
+        fresh._h = None
+        for p in self._params.values():
+            p._net = self
+        self._params._net = self
+        self._host, self._dev_params, self._ws, self._plan, self._device = {}, None, None, None, None
+        for k, v in new_vals.items():
+            self._params[k].set_data(v)
+        if device is not None:
+            self.reset_ctx(device)
+
+    def __deepcopy__(self, memo):
+        """``copy.deepcopy(net)`` (transforms.py:190): a host-side copy, not bound to a device."""
+        twin = YOLOV3(self._classes, self.nms_thresh, self.nms_topk, self.post_nms, self._pos_iou_thresh,
+                      self._ignore_iou_thresh, self._norm_layer, copy.deepcopy(self._norm_kwargs, memo),
+                      self._alloc_size)
+        if self._all_set():
+            for p in self._params.values():
+                twin._params[p.name].set_data(self._get_param(p.index))
+        twin._target_generator._label_smooth = self._target_generator._label_smooth
+        return twin
+
+    # ------------------------------------------------------------------ execution
+    def _ensure_plan(self, b, h, w):
+        torch = _torch()
+        if self._dev_params is None:
+            raise RuntimeError("parameters are not on a device: call net.collect_params().reset_ctx(ctx)")
+        if self._plan == (b, h, w):
+            return
+        need = self._lib.vy_net_workspace_bytes(self._h, b, h, w)
+        if need == 0:
+            raise _lib.VyError(-1, self._lib.vy_last_error().decode())
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = None
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self._device)
+        _lib.check(self._lib.vy_net_bind_workspace(self._h, ctypes.c_void_p(self._ws.data_ptr()),
+                                                   self._ws.numel(), b, h, w, self._stream()))
+        self._plan = (b, h, w)
+
+    def _as_input(self, x):
+        torch = _torch()
+        if not isinstance(x, torch.Tensor):
+            x = torch.as_tensor(np.asarray(x, np.float32))
+        if self._device is None:
+            raise RuntimeError("parameters are not on a device: call net.collect_params().reset_ctx(ctx)")
+        x = x.to(device=self._device, dtype=torch.float32).contiguous()
+        if x.dim() != 4 or x.shape[1] != 3:
+            raise ValueError("expected (B,3,H,W) input, got %s" % (tuple(x.shape),))
+        return x
+
+    def __call__(self, x, *args, return_index=False):
+        if autograd.is_training():
+            raise NotImplementedError(
+                "training-mode forward (yolo3.py:1179-1192) is not built yet in this round; "
+                "inference: call outside autograd.record()/train_mode()")
+        return self.detect(x, return_index=return_index)
+
+    def detect(self, x, return_index=False):
+        """Inference branch of YOLOV3T.hybrid_forward (yolo3.py:1194-1206): returns
+        (ids (B,R,1), scores (B,R,1), bboxes (B,R,4)) fp32 device tensors, R = post_nms."""
+        torch = _torch()
+        x = self._as_input(x)
+        b, _, h, w = x.shape
+        with torch.cuda.device(self._device):
+            self._ensure_plan(b, h, w)
+            rows = self.post_nms if self.post_nms > 0 else self.nms_topk
+            ids = torch.empty((b, rows, 1), dtype=torch.float32, device=self._device)
+            scores = torch.empty((b, rows, 1), dtype=torch.float32, device=self._device)
+            bboxes = torch.empty((b, rows, 4), dtype=torch.float32, device=self._device)
+            keep = torch.empty((b, rows), dtype=torch.int32, device=self._device) if return_index else None
+            _lib.check(self._lib.vy_net_forward_infer(
+                self._h, ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(ids.data_ptr()),
+                ctypes.c_void_p(scores.data_ptr()), ctypes.c_void_p(bboxes.data_ptr()),
+                ctypes.c_void_p(keep.data_ptr()) if keep is not None else None, self._stream()))
+        if return_index:
+            return ids, scores, bboxes, keep
+        return ids, scores, bboxes
+
+    def read_head(self, i):
+        """Prediction-conv output of head i (stride 32,16,8) of the last forward, NCHW."""
+        torch = _torch()
+        b, h, w = self._plan
+        div = (32, 16, 8)[i]
+        out = torch.empty((b, 3 * (5 + len(self._classes)), h // div, w // div), dtype=torch.float32,
+                          device=self._device)
+        with torch.cuda.device(self._device):
+            _lib.check(self._lib.vy_net_read_head(self._h, i, ctypes.c_void_p(out.data_ptr()), self._stream()))
+        return out
+
+    def read_activation(self, name):
+        """Output of cell `name` (e.g. 'stages.0.14.body.1') of the last forward, NCHW."""
+        torch = _torch()
+        c, h, w = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
+        _lib.check(self._lib.vy_net_read_activation(self._h, name.encode(), None, ctypes.byref(c),
+                                                    ctypes.byref(h), ctypes.byref(w), None))
+        out = torch.empty((self._plan[0], c.value, h.value, w.value), dtype=torch.float32, device=self._device)
+        with torch.cuda.device(self._device):
+            _lib.check(self._lib.vy_net_read_activation(self._h, name.encode(), ctypes.c_void_p(out.data_ptr()),
+                                                        None, None, None, self._stream()))
+        return out
+
+    def profile(self, x):
+        """One timed forward: list of (launch name, ms, flops, bytes) from HIP events around every
+        kernel launch on the current stream."""
+        torch = _torch()
+        x = self._as_input(x)
+        b, _, h, w = x.shape
+        with torch.cuda.device(self._device):
+            self._ensure_plan(b, h, w)
+            rows = self.post_nms if self.post_nms > 0 else self.nms_topk
+            ids = torch.empty((b, rows, 1), dtype=torch.float32, device=self._device)
+            scores = torch.empty_like(ids)
+            bboxes = torch.empty((b, rows, 4), dtype=torch.float32, device=self._device)
+            cap = 256
+            stats = (_lib.LaunchStat * cap)()
+            n = ctypes.c_int32(cap)
+            _lib.check(self._lib.vy_net_profile_infer(
+                self._h, ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(ids.data_ptr()),
+                ctypes.c_void_p(scores.data_ptr()), ctypes.c_void_p(bboxes.data_ptr()), stats,
+                ctypes.byref(n), self._stream()))
+        return [(stats[i].name.decode(), float(stats[i].ms), float(stats[i].flops), float(stats[i].bytes))
+                for i in range(n.value)]
+
+    def summary(self, *inputs):
+        """``net.summary(x)`` (train_yolov3.py:758): parameter table."""
+        total = 0
+        lines = []
+        for p in self._params.values():
+            lines.append("%-44s %-22s %10d" % (p.name, p.shape, p.size))
+            if p.trainable:
+                total += p.size
+        lines.append("trainable parameters: %d" % total)
+        print("\n".join(lines))
+
+
+# the reference class names
+YOLOV3T = YOLOV3
+
+
+def yolo3_darknet53(classes, pretrained_base=True, norm_layer=BatchNorm, norm_kwargs=None, freeze_base=False,
+                    k=None, k_join_type=None, k_join_pos=None, block_conv_type='2', rnn_pos=None,
+                    corr_pos=None, corr_d=None, motion_stream=None, add_type=None, agnostic=False,
+                    new_model=False, hierarchical=(1, 1, 1, 1, 1), h_join_type=None, temporal=False,
+                    t_out=False, **kwargs):
+    """Drop-in for models/definitions/yolo/wrappers.py:9-110 on the default (k=1) branch.
+
+    Only the arguments that select the hot path are honoured; a non-default value for any
+    temporal / two-stream / hierarchical option raises NotImplementedError (out of scope).
+    ``pretrained_base=True`` cannot be honoured offline (gluoncv model zoo download,
+    three_darknet.py:262): it warns and leaves the backbone to ``initialize()`` / ``load_parameters``.
+    """
+    unsupported = {
+        "k": k not in (None, 1), "k_join_type": k_join_type is not None, "k_join_pos": k_join_pos is not None,
+        "block_conv_type": str(block_conv_type) != '2', "rnn_pos": rnn_pos is not None,
+        "corr_pos": corr_pos is not None, "corr_d": corr_d is not None, "motion_stream": motion_stream is not None,
+        "add_type": add_type is not None, "agnostic": bool(agnostic), "new_model": bool(new_model),
+        "hierarchical": any(int(h) != 1 for h in hierarchical), "h_join_type": h_join_type is not None,
+        "temporal": bool(temporal), "t_out": bool(t_out)}
+    bad = [n for n, v in unsupported.items() if v]
+    if bad:
+        raise NotImplementedError(
+            "yolo3_darknet53: option(s) %s select a temporal/two-stream research variant outside the "
+            "MI355X hot path" % ", ".join(bad))
+    if pretrained_base:
+        warnings.warn("pretrained_base=True: no model-zoo access offline; backbone left uninitialised")
+    net = YOLOV3(classes, norm_layer=norm_layer, norm_kwargs=norm_kwargs, **kwargs)
+    if freeze_base:  # wrappers.py:55-57
+        for p in net.collect_params().values():
+            if p.backbone:
+                p.grad_req = 'null'
+    return net
