@@ -1,0 +1,174 @@
+#!/usr/bin/env python3
+"""bench.py — frames/sec of the yolo3_darknet53 hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--size 608] [--batch 64] [--classes 20]
+
+One "step" = one inference pass of the whole path (stem + 74 fused conv launches + decode + NMS)
+over one batch of synthetic frames that is already resident in HBM.  Default workload is
+BASELINE.json configs[1]: 608x608, batch 64 per GPU, 20 classes, fp32, random-init weights
+(videoyolo_amd.init 'synthetic', seed 233), N(0,1) frames.  With --gpus N the driver starts one
+process per GPU (torch.distributed.run); frames are scattered, every rank runs its own batch
+(weak scaling, no data-path collective — SURVEY §8e "Inference"), the timed region is bracketed
+by barrier + synchronize and the max over ranks is reported.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+  roofline      the dominant kernel (the 128x128 implicit-GEMM conv) against the fp32 MFMA peak,
+                from HIP events recorded around every launch of one extra, un-timed pass
+  cpu_baseline  the CPU oracle (oracle/, a port — NOT MXNet) timed on a bounded sample
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs @ 2.4 GHz
+HBM_PEAK_GBS = 8000.0
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--size", type=int, default=608)
+    ap.add_argument("--batch", type=int, default=64, help="frames per GPU per step")
+    ap.add_argument("--classes", type=int, default=20)
+    ap.add_argument("--obj-bias", type=float, default=0.0,
+                    help="added to the objectness biases (-5: trained-like sparse candidates)")
+    ap.add_argument("--cpu-frames", type=int, default=4, help="frames of the CPU-oracle sample (0: skip)")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import videoyolo_amd as vy
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be started by torch.distributed.run with %d ranks" %
+                     (args.gpus, args.gpus))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local))
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+
+    classes = ["c%d" % i for i in range(args.classes)]
+    net = vy.yolo3_darknet53(classes, pretrained_base=False)
+    net.initialize(init="synthetic", seed=233, obj_bias=args.obj_bias)
+    net.collect_params().reset_ctx(dev)
+    net.set_nms(0.45, 400, 100)
+    net.hybridize()
+
+    g = torch.Generator(device="cpu").manual_seed(233 + rank)
+    x = torch.randn((args.batch, 3, args.size, args.size), generator=g, dtype=torch.float32).to(dev)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        net(x)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = net(x)
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    frames = args.batch * world * args.steps
+    fps = frames / dt
+
+    result = {
+        "metric": "frames/sec, yolo3_darknet53 inference %dx%d" % (args.size, args.size),
+        "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "BASELINE.json configs[1]: Darknet-53 + 3-scale head + decode + NMS "
+                               "inference, %dx%d, batch %d per GPU, %d classes, nms 0.45/topk 400/post 100"
+                               % (args.size, args.size, args.batch, args.classes),
+                   "per_gpu_batch": args.batch, "global_batch": args.batch * world, "size": args.size,
+                   "classes": args.classes, "parallelism": "frame-scatter x%d" % world,
+                   "kept_detections_rank0": int((out[0] >= 0).sum().item())},
+    }
+
+    if rank == 0 and not args.no_roofline:
+        # per-launch HIP-event timing of extra passes (same stream the kernels run on)
+        passes = [net.profile(x) for _ in range(3)]
+        names = [p[0] for p in passes[0]]
+        med = []
+        for j in range(len(names)):
+            ms = sorted(p[j][1] for p in passes)[1]
+            med.append((names[j], ms, passes[0][j][2], passes[0][j][3]))
+        pinfo = {p.name: p for p in net.collect_params().values()}
+
+        def variant(name):
+            w = pinfo.get(name + ".0.weight") or pinfo.get(name + ".weight")
+            if w is None or w.shape[1] == 3:
+                return None
+            return "128x32" if w.shape[0] <= 32 else ("128x64" if w.shape[0] <= 64 else "128x128")
+        agg = {}
+        for name, ms, fl, by in med:
+            v = variant(name)
+            key = ("conv_igemm_kernel<%s>" % v) if v else ("stem_kernel" if name == "stages.0.0" else name)
+            a = agg.setdefault(key, [0, 0.0, 0.0, 0.0])
+            a[0] += 1
+            a[1] += ms
+            a[2] += fl
+            a[3] += by
+        dom = "conv_igemm_kernel<128x128>"
+        n, ms, fl, by = agg[dom]
+        achieved = fl / (ms * 1e-3) / 1e12
+        total_ms = sum(a[1] for a in agg.values())
+        total_fl = sum(a[2] for a in agg.values())
+        result["roofline"] = {
+            "bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+            "kernel": dom, "launches_per_step": n, "avg_launch_ms": ms / n,
+            "flops_per_launch_avg": fl / n, "kernel_share_of_step_time": ms / total_ms,
+            "whole_step_tflops": total_fl / (total_ms * 1e-3) / 1e12,
+            "by_kernel_ms": {k: round(a[1], 4) for k, a in agg.items()},
+        }
+        tail = agg.get("decode_nms")
+        if tail:
+            result["roofline"]["decode_nms"] = {
+                "ms": tail[1], "algorithmic_GBps": tail[3] / (tail[1] * 1e-3) / 1e9, "hbm_peak_GBps": HBM_PEAK_GBS}
+
+    if rank == 0 and args.cpu_frames > 0:
+        # CPU baseline: the oracle (a port of the same algorithm; NOT the reference's MXNet path,
+        # which cannot be installed here) on a bounded sample of the same workload
+        from oracle import yolo3_oracle as O
+        params = {p.name: p.data() for p in net.collect_params().values()}
+        orc = O.OracleYolo3(args.classes, params)
+        xs = x[:args.cpu_frames].cpu().numpy()
+        t0 = time.perf_counter()
+        orc(xs)
+        cdt = time.perf_counter() - t0
+        result["cpu_baseline"] = {
+            "value": args.cpu_frames / cdt, "unit": "frames/s", "cores": int(O.lib().vyo_num_threads()),
+            "kind": "port",
+            "sample": "%d frames of the same %dx%d batch through oracle/ (C + OpenMP conv, numpy graph, "
+                      "C NMS); MXNet itself is not installable here" % (args.cpu_frames, args.size, args.size)}
+
+    if rank == 0:
+        print(json.dumps(result))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
