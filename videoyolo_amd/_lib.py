@@ -66,6 +66,10 @@ def load():
         raise ImportError(
             "%s not found: build the HIP library first (python -m videoyolo_amd.build). "
             "videoyolo_amd has no CPU fallback." % LIB_PATH)
+    # torch ships its own libamdhip64; it must be the one HIP runtime of the process, so it is
+    # loaded first and libvyolo.so binds to it (loading /opt/rocm's copy first leaves torch without
+    # a device).  torch is the plumbing for device memory / streams anyway.
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
