@@ -1,0 +1,90 @@
+"""-m "not gpu": libvyolo.so loads and exports every symbol include/vyolo.h declares; the host-only
+entry points (graph construction, parameter table, planning, argument checking) behave.  No
+compute entry point is called here (there is no GPU in this container)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from videoyolo_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_functions():
+    src = open(os.path.join(ROOT, "include", "vyolo.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(vy_[a-z_0-9]+)\s*\(", src)))
+
+
+def test_every_declared_symbol_is_exported_and_bound():
+    lib = _lib.load()
+    names = _header_functions()
+    assert len(names) >= 18
+    for n in names:
+        assert hasattr(lib, n), "libvyolo.so does not export %s" % n
+    assert set(names) == set(_lib.SIGNATURES), (set(names) ^ set(_lib.SIGNATURES))
+    assert lib.vy_version().decode().endswith("gfx950")
+
+
+def test_product_does_not_touch_the_oracle():
+    """The product path must never route through oracle/ (or any CPU fallback)."""
+    pkg = os.path.join(ROOT, "videoyolo_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                text = open(os.path.join(dp, f)).read()
+                assert "oracle" not in text.replace("the oracle", "").replace("CPU checker", ""), (dp, f)
+
+
+@pytest.mark.parametrize("ncls,total", [(20, 61626049), (30, 61679899)])
+def test_param_table_matches_reference_structure(ncls, total):
+    from oracle import yolo3_oracle as O
+    lib = _lib.load()
+    h = ctypes.c_void_p()
+    _lib.check(lib.vy_net_create(ncls, ctypes.byref(h)))
+    n = lib.vy_net_num_params(h)
+    table, train, end = {}, 0, 0
+    for i in range(n):
+        info = _lib.ParamInfo()
+        _lib.check(lib.vy_net_param_info(h, i, ctypes.byref(info)))
+        shape = tuple(info.shape[j] for j in range(info.ndim))
+        table[info.name.decode()] = shape
+        assert info.size == int(np.prod(shape))
+        assert info.offset >= end and info.offset % 64 == 0   # disjoint, 256-B aligned
+        end = info.offset + info.size
+        if info.trainable:
+            train += info.size
+        assert info.backbone == int(info.name.decode().startswith("stages."))
+    assert table == dict(O.param_shapes(ncls))
+    assert train == total
+    assert lib.vy_net_param_bytes(h) >= end * 4
+    lib.vy_net_destroy(h)
+
+
+def test_planning_and_argument_errors():
+    lib = _lib.load()
+    h = ctypes.c_void_p()
+    _lib.check(lib.vy_net_create(20, ctypes.byref(h)))
+    b1 = lib.vy_net_workspace_bytes(h, 1, 416, 416)
+    b2 = lib.vy_net_workspace_bytes(h, 2, 416, 416)
+    b608 = lib.vy_net_workspace_bytes(h, 1, 608, 608)
+    # conv-output activations: 38.6 M floats / frame at 416 + borders + scratch
+    assert 38.6e6 * 4 < b1 < 1.25 * 38.6e6 * 4 + 4e6
+    assert b1 < b2 < 2 * b1 + 1e6 and b608 > 2 * b1
+    assert lib.vy_net_workspace_bytes(h, 1, 400, 416) == 0      # not a multiple of 32
+    assert "multiples of 32" in lib.vy_last_error().decode()
+    assert lib.vy_net_workspace_bytes(h, 0, 416, 416) == 0
+    rc = lib.vy_net_bind_workspace(h, None, 0, 1, 416, 416, None)
+    assert rc == -1
+    # forward before binding anything: a state error, not a crash
+    dummy = ctypes.c_void_p(16)
+    rc = lib.vy_net_forward_infer(h, dummy, dummy, dummy, dummy, None, None)
+    assert rc == -2 and "not bound" in lib.vy_last_error().decode()
+    info = _lib.ParamInfo()
+    assert lib.vy_net_param_info(h, 10 ** 6, ctypes.byref(info)) == -1
+    lib.vy_net_destroy(h)
+    bad = ctypes.c_void_p()
+    assert lib.vy_net_create(0, ctypes.byref(bad)) == -1

@@ -1,0 +1,126 @@
+"""-m "not gpu": the Python model object's host logic — the Gluon surface the reference's drivers
+call — without touching a device."""
+import copy
+import os
+
+import numpy as np
+import pytest
+
+import videoyolo_amd as vy
+from videoyolo_amd import autograd
+
+
+def _net(classes, **kw):
+    return vy.yolo3_darknet53(classes, pretrained_base=False, **kw)
+
+
+def test_constructor_contract(voc_classes):
+    net = _net(voc_classes)
+    assert net.classes == voc_classes and net.num_class == 20
+    assert (net.nms_thresh, net.nms_topk, net.post_nms) == (0.45, 400, 100)   # yolo3.py:959-963
+    for bad in [dict(k=3), dict(motion_stream="flownet"), dict(temporal=True), dict(block_conv_type='3'),
+                dict(new_model=True), dict(agnostic=True), dict(hierarchical=[3, 1, 1, 1, 1])]:
+        with pytest.raises(NotImplementedError):
+            _net(voc_classes, **bad)
+    with pytest.raises(NotImplementedError):
+        vy.YOLOV3(voc_classes, pos_iou_thresh=0.5)                             # yolo3.py:990-992
+    _net(voc_classes, k=1, norm_layer=vy.SyncBatchNorm, norm_kwargs={"num_devices": 8})
+    with pytest.warns(UserWarning):
+        vy.yolo3_darknet53(voc_classes, pretrained_base=True)
+
+
+def test_collect_params_select_and_freeze(voc_classes):
+    net = _net(voc_classes, freeze_base=True)
+    ps = net.collect_params()
+    assert len(ps) == 366
+    sel = net.collect_params('.*beta|.*gamma|.*bias')                          # train_yolov3.py:496
+    assert len(sel) == 72 * 2 + 3
+    for p in sel.values():
+        p.wd_mult = 0.0
+    assert ps["stages.0.0.1.gamma"].wd_mult == 0.0 and ps["stages.0.0.0.weight"].wd_mult == 1.0
+    frozen = [p for p in ps.values() if p.grad_req == 'null']
+    assert all(p.name.startswith("stages.") or not p.trainable for p in frozen)
+    assert ps["stages.2.4.body.1.0.weight"].grad_req == 'null'                # wrappers.py:55-57
+    assert ps["yolo_blocks.0.body.0.0.weight"].grad_req == 'write'
+    assert ps["stages.0.0.1.running_mean"].grad_req == 'null'
+
+
+def test_initialize_save_load_roundtrip(voc_classes, tmp_path):
+    net = _net(voc_classes)
+    with pytest.raises(RuntimeError):
+        net.collect_params()["stages.0.0.0.weight"].data()
+    net.initialize()
+    w = net.collect_params()["stages.0.0.0.weight"].data()
+    assert w.shape == (32, 3, 3, 3) and np.abs(w).max() <= 0.07
+    assert np.all(net.collect_params()["stages.0.0.1.gamma"].data() == 1)
+    net.initialize(init="synthetic", force_reinit=True, seed=1)
+    f = str(tmp_path / "yolo3_darknet53_voc_0000.params")
+    net.save_parameters(f)
+    twin = _net(voc_classes)
+    twin.load_parameters(f)
+    for k, p in net.collect_params().items():
+        assert np.array_equal(p.data(), twin.collect_params()[k].data())
+    other = _net(voc_classes[:3])
+    with pytest.raises(ValueError):
+        other.load_parameters(f)  # prediction shapes differ
+    with pytest.raises(AssertionError):
+        twin.set_parameters({"stages.0.0.0.weight": w})  # missing others
+    twin.set_parameters({"stages.0.0.0.weight": w * 2}, allow_missing=True)
+    assert np.array_equal(twin.collect_params()["stages.0.0.0.weight"].data(), w * 2)
+
+
+def test_reset_class_reuses_rows(voc_classes):
+    """yolo3.py:76-129: new[1+4+k + a*P_new] = old[1+4+v + a*P_old]; box/objectness rows copied."""
+    net = _net(voc_classes)
+    net.initialize(init="synthetic", seed=3)
+    old_w = net.collect_params()["yolo_outputs.1.prediction.weight"].data()
+    old_b = net.collect_params()["yolo_outputs.1.prediction.bias"].data()
+    keep_backbone = net.collect_params()["stages.1.3.body.0.0.weight"].data()
+    net.reset_class(["person", "mug"], reuse_weights={"person": "person"})    # person = VOC index 14
+    assert net.classes == ["person", "mug"]
+    new_w = net.collect_params()["yolo_outputs.1.prediction.weight"].data()
+    new_b = net.collect_params()["yolo_outputs.1.prediction.bias"].data()
+    assert new_w.shape == (3 * 7, 512, 1, 1)
+    for a in range(3):
+        assert np.array_equal(new_w[a * 7:a * 7 + 5], old_w[a * 25:a * 25 + 5])
+        assert np.array_equal(new_w[a * 7 + 5], old_w[a * 25 + 5 + 14])
+        assert np.array_equal(new_b[a * 7 + 5], old_b[a * 25 + 5 + 14])
+    assert np.array_equal(net.collect_params()["stages.1.3.body.0.0.weight"].data(), keep_backbone)
+    with pytest.raises(ValueError):
+        net.reset_class(["x"], reuse_weights={"x": "nonexistent"})
+    with pytest.raises(ValueError):
+        net.reset_class(["x"], reuse_weights={0: 99})
+    net.reset_class(["person"], reuse_weights=["person"])
+    assert net.collect_params()["yolo_outputs.0.prediction.bias"].shape == (18,)
+
+
+def test_deepcopy_is_host_side_and_independent(voc_classes):
+    net = _net(voc_classes[:4])
+    net.initialize(init="synthetic", seed=2)
+    net._target_generator._label_smooth = True                                  # train_yolov3.py:500
+    twin = copy.deepcopy(net)                                                   # transforms.py:190
+    assert twin._target_generator._label_smooth is True
+    a = net.collect_params()["transitions.0.0.weight"]
+    b = twin.collect_params()["transitions.0.0.weight"]
+    assert np.array_equal(a.data(), b.data())
+    b.set_data(b.data() * 0)
+    assert np.abs(a.data()).sum() > 0
+
+
+def test_modes_and_errors_without_device(voc_classes):
+    net = _net(voc_classes[:2])
+    net.initialize()
+    net.hybridize()
+    net.set_nms(nms_thresh=0.3, nms_topk=200, post_nms=50)
+    assert (net.nms_thresh, net.nms_topk, net.post_nms) == (0.3, 200, 50)
+    assert not autograd.is_training() and not autograd.is_recording()
+    with autograd.record():
+        assert autograd.is_training() and autograd.is_recording()
+        with autograd.pause():
+            assert not autograd.is_recording() and not autograd.is_training()
+    with autograd.train_mode():
+        assert autograd.is_training() and not autograd.is_recording()
+    with pytest.raises(RuntimeError, match="not on a device"):
+        net(np.zeros((1, 3, 64, 64), np.float32))
+    with pytest.raises(RuntimeError):
+        net.collect_params().reset_ctx("cpu")                                   # no CPU path

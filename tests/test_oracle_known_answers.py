@@ -1,0 +1,205 @@
+"""Pins for the CPU oracle (oracle/).  The reference has no tests or golden vectors for this path
+and mxnet/gluoncv cannot run here, so the oracle is pinned by cases small enough
+to derive by hand (expected values are written out, with the derivation) and by float64
+brute-force restatements of the operator definitions."""
+import numpy as np
+import pytest
+
+from oracle import yolo3_oracle as O
+
+
+def test_vy_math_against_libm():
+    x = np.linspace(-80, 80, 20001).astype(np.float32)
+    e = O.exp(x).astype(np.float64)
+    ref = np.exp(x.astype(np.float64))
+    assert np.max(np.abs(e - ref) / ref) < 2.0 * 2 ** -23  # <= 2 ulp
+    s = O.sigmoid(x).astype(np.float64)
+    assert np.max(np.abs(s - 1 / (1 + np.exp(-x.astype(np.float64))))) < 2e-7
+    y = np.exp(np.linspace(-60, 60, 20001)).astype(np.float32)
+    l = O.log(y).astype(np.float64)
+    assert np.max(np.abs(l - np.log(y.astype(np.float64)))) < 4e-6 * 1 + 2e-7 * np.max(np.abs(l))
+    assert O.sigmoid(np.zeros(1, np.float32))[0] == 0.5
+    assert O.exp(np.zeros(1, np.float32))[0] == 1.0
+    assert O.exp(np.array([100.0], np.float32))[0] == np.inf
+    assert O.exp(np.array([-100.0], np.float32))[0] == 0.0
+
+
+def test_conv_1x1_by_hand():
+    # y[o] = sum_c w[o,c] x[c]:  x = [1,2,3] at every pixel, w = [[1,0,-1],[0.5,0.5,0.5]] -> [-2, 3]
+    x = np.ones((1, 3, 2, 2), np.float32) * np.array([1, 2, 3], np.float32).reshape(1, 3, 1, 1)
+    w = np.array([[1, 0, -1], [0.5, 0.5, 0.5]], np.float32).reshape(2, 3, 1, 1)
+    y = O.conv2d(x, w, 1, 0)
+    assert y.shape == (1, 2, 2, 2)
+    assert np.array_equal(y[0, 0], np.full((2, 2), -2.0)) and np.array_equal(y[0, 1], np.full((2, 2), 3.0))
+
+
+def test_conv_3x3_padding_and_stride_by_hand():
+    # all-ones 3x3 kernel on a 4x4 all-ones image, pad 1: each output counts the taps inside the image
+    x = np.ones((1, 1, 4, 4), np.float32)
+    w = np.ones((1, 1, 3, 3), np.float32)
+    y = O.conv2d(x, w, 1, 1)[0, 0]
+    want = np.array([[4, 6, 6, 4], [6, 9, 9, 6], [6, 9, 9, 6], [4, 6, 6, 4]], np.float32)
+    assert np.array_equal(y, want)
+    # stride 2, pad 1: output (2,2) sampled at input centres (0,0),(0,2),(2,0),(2,2)
+    y2 = O.conv2d(x, w, 2, 1)[0, 0]
+    assert np.array_equal(y2, np.array([[4, 6], [6, 9]], np.float32))
+    # cross-correlation (no kernel flip): kernel with a single 1 at (kh=0,kw=2) picks x[y-1, x+1]
+    img = np.arange(16, dtype=np.float32).reshape(1, 1, 4, 4)
+    k = np.zeros((1, 1, 3, 3), np.float32)
+    k[0, 0, 0, 2] = 1
+    y3 = O.conv2d(img, k, 1, 1)[0, 0]
+    want3 = np.zeros((4, 4), np.float32)
+    want3[1:, :3] = img[0, 0, :3, 1:]
+    assert np.array_equal(y3, want3)
+
+
+@pytest.mark.parametrize("k,s,cin,cout,h", [(3, 1, 5, 4, 7), (3, 2, 3, 6, 8), (1, 1, 8, 3, 5)])
+def test_conv_against_float64_bruteforce(k, s, cin, cout, h):
+    rng = np.random.default_rng(k * 10 + s)
+    x = rng.standard_normal((2, cin, h, h)).astype(np.float32)
+    w = rng.standard_normal((cout, cin, k, k)).astype(np.float32)
+    p = k // 2
+    y = O.conv2d(x, w, s, p)
+    xp = np.pad(x.astype(np.float64), ((0, 0), (0, 0), (p, p), (p, p)))
+    ho = (h + 2 * p - k) // s + 1
+    ref = np.zeros((2, cout, ho, ho))
+    for oy in range(ho):
+        for ox in range(ho):
+            patch = xp[:, :, oy * s:oy * s + k, ox * s:ox * s + k]
+            ref[:, :, oy, ox] = np.einsum('nchw,ochw->no', patch, w.astype(np.float64))
+    assert y.shape == ref.shape
+    np.testing.assert_allclose(y, ref, rtol=0, atol=2e-5)
+
+
+def test_conv_epilogue_and_bn_fold_by_hand():
+    # gamma 2, var 3 (eps 1): scale = 2/sqrt(4) = 1 ; mean 5, beta 1: shift = 1 - 5*1 = -4
+    sc, sh = O.bn_fold([2.0], [1.0], [5.0], [3.0], eps=1.0)
+    assert sc[0] == 1.0 and sh[0] == -4.0
+    # conv result 3 at every pixel -> affine 3*1-4 = -1 -> leaky 0.1*(-1) = -0.1 ; result 6 -> 2 stays 2
+    x = np.ones((1, 1, 1, 2), np.float32) * np.array([3.0, 6.0], np.float32)
+    y = O.conv2d(x, np.ones((1, 1, 1, 1), np.float32), 1, 0, sc, sh, leaky=True)
+    assert y[0, 0, 0, 0] == np.float32(0.1) * np.float32(-1.0) and y[0, 0, 0, 1] == 2.0
+    # bias-only epilogue (prediction conv, yolo3.py:62)
+    y = O.conv2d(x, np.ones((1, 1, 1, 1), np.float32), 1, 0, None, np.array([0.5], np.float32))
+    assert np.array_equal(y.ravel(), [3.5, 6.5])
+
+
+def test_bn_train_by_hand():
+    # one channel, values 1,2,3,4 -> mean 2.5, biased var 1.25
+    x = np.array([1, 2, 3, 4], np.float32).reshape(1, 1, 2, 2)
+    y, m, v = O.bn_train(x, [1.0], [0.0], eps=0.0, leaky=False)
+    assert m[0] == 2.5 and v[0] == 1.25
+    np.testing.assert_allclose(y.ravel(), (np.array([1, 2, 3, 4]) - 2.5) / np.sqrt(1.25), atol=1e-6)
+
+
+def _tiny_net(num_class=2):
+    params = {n: np.zeros(s, np.float32) for n, s in O.param_shapes(num_class)}
+    for n in params:
+        if n.endswith(("gamma", "running_var")):
+            params[n][...] = 1
+    return params
+
+
+def test_decode_zero_prediction_by_hand():
+    """All-zero prediction conv => raw = 0 everywhere: sigmoid 0.5, exp 1.  At the stride-32 head of
+    a 64x64 input (2x2 grid), anchor a of cell (x,y): centre ((0.5+x)*32, (0.5+y)*32), size =
+    anchor (116,90),(156,198),(373,326); score = 0.5*0.5 = 0.25; layout class-major, then cell
+    (y*W+x), then anchor (yolo3.py:191-197)."""
+    C = 2
+    net = O.OracleYolo3(C, _tiny_net(C))
+    det = net.output(np.zeros((1, 1024, 2, 2), np.float32), 0)
+    assert det.shape == (1, C * 2 * 2 * 3, 6)
+    anchors = [(116, 90), (156, 198), (373, 326)]
+    r = 0
+    for c in range(C):
+        for y in range(2):
+            for x in range(2):
+                for a, (aw, ah) in enumerate(anchors):
+                    cx, cy = (0.5 + x) * 32, (0.5 + y) * 32
+                    want = [c, 0.25, cx - aw / 2, cy - ah / 2, cx + aw / 2, cy + ah / 2]
+                    assert np.array_equal(det[0, r], np.array(want, np.float32)), (r, det[0, r], want)
+                    r += 1
+
+
+def test_head_order_and_upsample_concat():
+    """Scales are concatenated stride 32, 16, 8 (yolo3.py:1195) and N = 3*sum(H_i*W_i)."""
+    C = 1
+    net = O.OracleYolo3(C, _tiny_net(C))
+    d = net.detections(np.zeros((1, 3, 64, 64), np.float32))
+    n = 3 * (2 * 2 + 4 * 4 + 8 * 8)
+    assert d.shape == (1, n * C, 6)
+    # first row = stride-32 head cell (0,0) anchor 0: width 116; row 12 = stride-16 head: width 30
+    assert d[0, 0, 4] - d[0, 0, 2] == 116 and d[0, 12, 4] - d[0, 12, 2] == 30
+    assert d[0, 12 + 48, 4] - d[0, 12 + 48, 2] == 10
+    # _upsample (layers.py:20): repeat along W then H
+    x = np.arange(4, dtype=np.float32).reshape(1, 1, 2, 2)
+    up = x.repeat(2, axis=-1).repeat(2, axis=-2)
+    assert np.array_equal(up[0, 0], [[0, 0, 1, 1], [0, 0, 1, 1], [2, 2, 3, 3], [2, 2, 3, 3]])
+
+
+def _nms(rows, **kw):
+    out, idx = O.box_nms(np.array(rows, np.float32)[None], **kw)
+    return out[0], idx[0]
+
+
+def test_nms_by_hand():
+    rows = [
+        [0, 0.90, 0, 0, 10, 10],     # 0 keep
+        [0, 0.80, 1, 1, 11, 11],     # 1 IoU with 0 = 81/119 = 0.68 > 0.45, same class -> suppressed
+        [1, 0.85, 1, 1, 11, 11],     # 2 other class -> kept (force_suppress False)
+        [0, 0.70, 20, 20, 30, 30],   # 3 disjoint -> kept
+        [0, 0.005, 0, 0, 10, 10],    # 4 below valid_thresh 0.01
+        [0, 0.01, 50, 50, 60, 60],   # 5 score == valid_thresh: NOT valid (strict >)
+        [-1, -1, -1, -1, -1, -1],    # 6 padding row
+        [0, 0.60, 0, 5, 10, 15],     # 7 IoU with 0 = 50/150 = 0.333 -> kept
+    ]
+    out, idx = _nms(rows, overlap_thresh=0.45, valid_thresh=0.01, topk=400)
+    assert list(idx) == [0, 2, 3, 7, -1, -1, -1, -1]
+    assert np.array_equal(out[:4, 1], np.array([0.9, 0.85, 0.7, 0.6], np.float32))
+    assert (out[4:] == -1).all()
+    # topk = 2: only rows 0 and 2 (the two best) take part at all
+    out, idx = _nms(rows, overlap_thresh=0.45, valid_thresh=0.01, topk=2)
+    assert list(idx) == [0, 2, -1, -1, -1, -1, -1, -1]
+    # force_suppress: class ignored, row 2 now dies too
+    out, idx = _nms(rows, overlap_thresh=0.45, valid_thresh=0.01, topk=400, force_suppress=True)
+    assert list(idx) == [0, 3, 7, -1, -1, -1, -1, -1]
+
+
+def test_nms_iou_threshold_is_strict_and_ties_keep_input_order():
+    # IoU exactly 0.5 (boxes 0..10 and 0..10 x [0..5 union]) with thresh 0.5 -> not suppressed
+    rows = [[0, 0.9, 0, 0, 10, 10], [0, 0.8, 0, 0, 10, 5]]  # inter 50, union 100 -> 0.5
+    out, idx = _nms(rows, overlap_thresh=0.5, valid_thresh=0.01, topk=-1)
+    assert list(idx) == [0, 1]
+    # equal scores: ascending input row order
+    rows = [[0, 0.5, 0, 0, 1, 1], [1, 0.5, 5, 5, 6, 6], [2, 0.5, 9, 9, 10, 10]]
+    out, idx = _nms(rows, overlap_thresh=0.45, valid_thresh=0.01, topk=-1)
+    assert list(idx) == [0, 1, 2]
+    # suppression chains are greedy: B is killed by A, so C (overlapping only B) survives
+    rows = [[0, 0.9, 0, 0, 10, 10], [0, 0.8, 4, 0, 14, 10], [0, 0.7, 8, 0, 18, 10]]
+    out, idx = _nms(rows, overlap_thresh=0.4, valid_thresh=0.01, topk=-1)  # IoU(A,B)=60/140=.43 IoU(B,C)=.43 IoU(A,C)=20/180
+    assert list(idx) == [0, 2, -1]
+
+
+def test_batch_iou_by_hand():
+    a = np.array([[[0, 0, 10, 10], [0, 0, 2, 2]]], np.float32)
+    b = np.array([[[5, 5, 15, 15], [-1, -1, -1, -1]]], np.float32)
+    iou = O.batch_iou(a, b)
+    assert iou.shape == (1, 2, 2)
+    np.testing.assert_allclose(iou[0, 0, 0], 25.0 / 175.0, rtol=1e-6)
+    assert iou[0, 1, 0] == 0 and iou[0, 0, 1] == 0  # padded gt (-1 box has zero area, no overlap)
+
+
+def test_param_table_invariants():
+    """Structural invariants derived from the reference's layer definitions."""
+    for ncls, total in [(20, 61626049), (30, 61679899)]:
+        tab = O.param_shapes(ncls)
+        train = sum(int(np.prod(s)) for n, s in tab if not n.endswith(("running_mean", "running_var")))
+        assert train == total
+        assert sum(1 for n, s in tab if len(s) == 4) == 75            # conv layers
+        assert sum(1 for n, s in tab if n.endswith("gamma")) == 72     # with BN
+        k3 = sum(1 for n, s in tab if len(s) == 4 and s[2] == 3)
+        assert k3 == 38 and 75 - k3 == 37
+    names = [n for n, _ in O.param_shapes(20)]
+    assert "stages.0.0.0.weight" in names and "stages.2.4.body.1.1.running_var" in names
+    assert "yolo_blocks.2.tip.0.weight" in names and "transitions.1.1.gamma" in names
+    assert "yolo_outputs.0.prediction.bias" in names
