@@ -243,3 +243,61 @@ void vyo_batch_iou(const float* a, const float* b, int B, int N, int M, float* o
       }
     }
 }
+
+/* ---------------------------------------------------------------------------------------------
+ * Backward of Conv2D (what mxnet autograd computes for layers.py:66 / yolo3.py:62), written from
+ * the definition  y[n,o,oy,ox] = sum_{c,kh,kw} x[n,c,oy*s+kh-p,ox*s+kw-p] * w[o,c,kh,kw]:
+ *   dx[n,c,iy,ix] = sum_{o,kh,kw : iy = oy*s+kh-p, ix = ox*s+kw-p} dy[n,o,oy,ox] * w[o,c,kh,kw]
+ *   dw[o,c,kh,kw] = sum_{n,oy,ox} dy[n,o,oy,ox] * x[n,c,oy*s+kh-p,ox*s+kw-p]
+ * Accumulated in double: this side is the accuracy reference for the fp32 device kernels.
+ * ------------------------------------------------------------------------------------------- */
+void vyo_conv2d_bwd_data(const float* dy, int N, int O, int Ho, int Wo, const float* w, int C, int k,
+                         int s, int p, int H, int W, float* dx) {
+#pragma omp parallel for collapse(2) schedule(static)
+  for (int n = 0; n < N; ++n)
+    for (int c = 0; c < C; ++c) {
+      double* acc = (double*)calloc((size_t)H * W, sizeof(double));
+      for (int o = 0; o < O; ++o)
+        for (int kh = 0; kh < k; ++kh)
+          for (int kw = 0; kw < k; ++kw) {
+            const double wv = w[(((size_t)o * C + c) * k + kh) * k + kw];
+            for (int oy = 0; oy < Ho; ++oy) {
+              const int iy = oy * s + kh - p;
+              if (iy < 0 || iy >= H) continue;
+              const float* dr = dy + (((size_t)n * O + o) * Ho + oy) * Wo;
+              for (int ox = 0; ox < Wo; ++ox) {
+                const int ix = ox * s + kw - p;
+                if (ix < 0 || ix >= W) continue;
+                acc[(size_t)iy * W + ix] += wv * dr[ox];
+              }
+            }
+          }
+      float* out = dx + ((size_t)n * C + c) * H * W;
+      for (size_t i = 0; i < (size_t)H * W; ++i) out[i] = (float)acc[i];
+      free(acc);
+    }
+}
+
+void vyo_conv2d_bwd_weight(const float* dy, int N, int O, int Ho, int Wo, const float* x, int C, int k,
+                           int s, int p, int H, int W, float* dw) {
+#pragma omp parallel for collapse(2) schedule(static)
+  for (int o = 0; o < O; ++o)
+    for (int c = 0; c < C; ++c)
+      for (int kh = 0; kh < k; ++kh)
+        for (int kw = 0; kw < k; ++kw) {
+          double acc = 0;
+          for (int n = 0; n < N; ++n)
+            for (int oy = 0; oy < Ho; ++oy) {
+              const int iy = oy * s + kh - p;
+              if (iy < 0 || iy >= H) continue;
+              const float* dr = dy + (((size_t)n * O + o) * Ho + oy) * Wo;
+              const float* xr = x + (((size_t)n * C + c) * H + iy) * W;
+              for (int ox = 0; ox < Wo; ++ox) {
+                const int ix = ox * s + kw - p;
+                if (ix < 0 || ix >= W) continue;
+                acc += (double)dr[ox] * xr[ix];
+              }
+            }
+          dw[(((size_t)o * C + c) * k + kh) * k + kw] = (float)acc;
+        }
+}
