@@ -1,17 +1,21 @@
-// conv_igemm.hip — 3x3 / 1x1 convolution as an implicit GEMM on the gfx950 fp32 matrix core.
+// conv_igemm.hip — 3x3 / 1x1 convolution (forward and data-gradient) as an implicit GEMM on the
+// gfx950 fp32 matrix core.
 //
 // Replaces the mxnet operator chain behind the reference's `_conv2d` cell
 // (models/definitions/layers.py:63-70: Conv2D(no bias) -> BatchNorm -> LeakyReLU(0.1)), the
 // residual add of DarknetBasicBlockV3 (darknet/three_darknet.py:119-123), the 1x1 prediction conv
 // with bias (yolo/yolo3.py:62) and `_upsample` + concat (layers.py:11-20, yolo3.py:1167-1177), all
 // in ONE kernel: the affine / activation / residual / x2-replicate happen on the accumulator.
+// In training the same kernel produces the raw conv output plus per-tile channel sums for the
+// batch statistics, and (dgrad mode) the gradient w.r.t. the conv input that mxnet's autograd
+// computes for Convolution (train_yolov3.py:631).
 //
 // GEMM view:  D[m][n] = sum_k A[m][k] * W[n][k]
-//   m = (b, oy, ox) output pixel        M = B*Ho*Wo
-//   n = output channel                  N = Cout
-//   k = (kh, kw, cin)                   K = ks*ks*Cin, Cin % 32 == 0
+//   m = (b, y, x) pixel of a logical grid   M = B*LH*LW
+//   n = output channel                      N
+//   k = (tap, channel)                      K = ntaps*Kc, Kc % 32 == 0
 // A is never materialised: activations are zero-bordered NHWC planes (kernels.h), so the A row of
-// pixel m for tap (kh,kw) is 32 contiguous floats at a fixed offset from the pixel's base address.
+// pixel m for tap t is 32 contiguous floats at a fixed offset from the pixel's centre address.
 //
 // Numerics: v_mfma_f32_32x32x2_f32 is an exact fp32 fma chain in k order (k0 from lanes 0-31, k1
 // from lanes 32-63).  Each lane fetches 4 consecutive k with one ds_read_b128 and the two lane
@@ -20,9 +24,11 @@
 //
 // Tiling (MI355X): 256 threads = 4 waves; block tile 128 x BN x 32(k); per k-step the A and W
 // tiles (128 B per row) are brought in by LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave
-// instruction = 8 rows) into a double buffer; the 16-B chunk index is XOR-swizzled on the
-// SOURCE side with (row>>1)&7 so the ds_read_b128 of 32 different rows at one k-chunk is
-// bank-conflict free.  128x128 tile: 64 KiB of LDS -> 2 blocks / CU, 64 accumulator VGPRs / lane.
+// instruction) into a double buffer; the 16-B chunk index is XOR-swizzled on the SOURCE side with
+// (row>>1)&7 so the ds_read_b128 of 32 different rows at one k-chunk is bank-conflict free.
+// 128x128 tile: 64 KiB of LDS -> 2 blocks / CU, 64 accumulator VGPRs / lane.
+// dgrad reads W as the [k][n] operand: its LDS tile is 32 k-rows of BN contiguous floats, read with
+// ds_read_b32 (32 consecutive floats per half-wave: conflict-free without a swizzle).
 #include "kernels.h"
 #include "../../include/vy_math.h"
 
@@ -31,7 +37,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, bool DGRAD>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a, const int tiles_n) {
 #if defined(__HIP_DEVICE_COMPILE__)  // the host pass only needs the launch stub (amdgcn builtins below)
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
@@ -40,10 +46,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a, const
   static_assert(WM * WN == 4, "4 waves");
   static_assert(TM >= 1 && TN >= 1, "tile");
   // one LDS object: [stage0 A|W][stage1 A|W][row tables]
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE + 3 * BM * 8];
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE + 2 * BM * 8];
   long long* in_off = reinterpret_cast<long long*>(smem + 2 * STAGE);
-  long long* out_off = in_off + BM;
-  long long* res_off = out_off + BM;
+  long long* o_pix = in_off + BM;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -62,23 +67,15 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a, const
   const int tile_m = v / tiles_n, tile_n = v - tile_m * tiles_n;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
-  const int Hp = a.Hi + 2, Wp = a.Wi + 2;
-  const int K = a.ksize * a.ksize * a.Cin;
-
   if (tid < BM) {
     const int m = m0 + tid;
     const int mm = m < a.M ? m : a.M - 1;
-    const int ox = mm % a.Wo;
-    const int t = mm / a.Wo;
-    const int oy = t % a.Ho;
-    const int b = t / a.Ho;
-    const int o1 = (a.ksize == 1) ? 1 : 0;
-    in_off[tid] = ((long long)(b * Hp + oy * a.stride + o1) * Wp + ox * a.stride + o1) * a.in_cs + a.in_co;
-    const int Hop = a.Ho * a.ups + 2, Wop = a.Wo * a.ups + 2;
-    out_off[tid] = (m < a.M)
-                       ? ((long long)(b * Hop + oy * a.ups + 1) * Wop + ox * a.ups + 1) * a.out_cs + a.out_co
-                       : -1;
-    res_off[tid] = ((long long)(b * (a.Ho + 2) + oy + 1) * (a.Wo + 2) + ox + 1) * a.res_cs + a.res_co;
+    const int x = mm % a.LW;
+    const int t = mm / a.LW;
+    const int y = t % a.LH;
+    const int b = t / a.LH;
+    in_off[tid] = ((long long)(b * a.a_Hp + y * a.a_s + a.a_oy) * a.a_Wp + x * a.a_s + a.a_ox) * a.a_cs + a.a_co;
+    o_pix[tid] = (m < a.M) ? ((long long)(b * a.o_Hp + y * a.o_s + a.o_oy) * a.o_Wp + x * a.o_s + a.o_ox) : -1;
   }
   __syncthreads();
 
@@ -91,13 +88,26 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a, const
     const int chunk = (lane & 7) ^ ((row >> 1) & 7);
     a_src[j] = a.in + in_off[row] + chunk * 4;
   }
+  const int wK = a.w_taps * a.w_cin;  // floats per weight row (one cout)
+  int b_krow[B_INSTR];                // dgrad: k-row of this lane inside the 32-row W tile
 #pragma unroll
   for (int j = 0; j < B_INSTR; ++j) {
-    const int row = (j * 4 + wave) * 8 + (lane >> 3);
-    const int chunk = (lane & 7) ^ ((row >> 1) & 7);
-    int n = n0 + row;
-    n = n < a.Cout ? n : a.Cout - 1;
-    b_src[j] = a.w + (long long)n * K + chunk * 4;
+    if (!DGRAD) {
+      const int row = (j * 4 + wave) * 8 + (lane >> 3);
+      const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+      int n = n0 + row;
+      n = n < a.N ? n : a.N - 1;
+      b_src[j] = a.w + (long long)n * wK + chunk * 4;
+      b_krow[j] = 0;
+    } else {
+      constexpr int CPR = BN / 4;    // 16-B chunks per k-row
+      constexpr int RPI = 64 / CPR;  // k-rows per wave instruction
+      const int row = (j * 4 + wave) * RPI + lane / CPR;
+      int n = n0 + (lane % CPR) * 4;
+      n = n < a.N ? n : 0;
+      b_src[j] = a.w + n;
+      b_krow[j] = row;
+    }
   }
 
   f32x16 acc[TM][TN];
@@ -108,24 +118,32 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a, const
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-  const int cchunks = a.Cin >> 5;
-  const int T = a.ksize * a.ksize * cchunks;
+  const int cchunks = a.Kc >> 5;
+  const int T = a.ntaps * cchunks;
 
   auto stage = [&](int t, int buf) {
     const int tap = t / cchunks;
     const int cc = t - tap * cchunks;
-    const int kh = (a.ksize == 3) ? tap / 3 : 0;
-    const int kw = (a.ksize == 3) ? tap - kh * 3 : 0;
-    const long long a_koff = (long long)(kh * Wp + kw) * a.in_cs + cc * 32;
-    const int b_koff = t * 32;
+    const long long a_koff = (long long)((int)a.tap_dy[tap] * a.a_Wp + (int)a.tap_dx[tap]) * a.a_cs + cc * 32;
     unsigned char* sA = smem + buf * STAGE;
     unsigned char* sB = sA + A_BYTES;
 #pragma unroll
     for (int j = 0; j < A_INSTR; ++j)
       __builtin_amdgcn_global_load_lds(a_src[j] + a_koff, LDS_PTR(sA + (j * 4 + wave) * 1024), 16, 0, 0);
+    if (!DGRAD) {
+      const int b_koff = (int)a.tap_w[tap] * a.w_cin + cc * 32;
 #pragma unroll
-    for (int j = 0; j < B_INSTR; ++j)
-      __builtin_amdgcn_global_load_lds(b_src[j] + b_koff, LDS_PTR(sB + (j * 4 + wave) * 1024), 16, 0, 0);
+      for (int j = 0; j < B_INSTR; ++j)
+        __builtin_amdgcn_global_load_lds(b_src[j] + b_koff, LDS_PTR(sB + (j * 4 + wave) * 1024), 16, 0, 0);
+    } else {
+#pragma unroll
+      for (int j = 0; j < B_INSTR; ++j) {
+        int o = cc * 32 + b_krow[j];
+        o = o < a.w_cout ? o : a.w_cout - 1;  // padded k rows: A is zero there
+        const long long off = ((long long)o * a.w_taps + (int)a.tap_w[tap]) * a.w_cin;
+        __builtin_amdgcn_global_load_lds(b_src[j] + off, LDS_PTR(sB + (j * 4 + wave) * 1024), 16, 0, 0);
+      }
+    }
   };
 
   stage(0, 0);
@@ -149,10 +167,17 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a, const
       }
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
-        const int row = (wn * TN + j) * 32 + lrow;
-        const f32x4 q = *reinterpret_cast<const f32x4*>(sB + row * 128 + ((kk ^ ((row >> 1) & 7)) << 4));
-        blo[j] = h ? q[1] : q[0];
-        bhi[j] = h ? q[3] : q[2];
+        if (!DGRAD) {
+          const int row = (wn * TN + j) * 32 + lrow;
+          const f32x4 q = *reinterpret_cast<const f32x4*>(sB + row * 128 + ((kk ^ ((row >> 1) & 7)) << 4));
+          blo[j] = h ? q[1] : q[0];
+          bhi[j] = h ? q[3] : q[2];
+        } else {
+          const int col = (wn * TN + j) * 32 + lrow;
+          const float* tb = reinterpret_cast<const float*>(sB);
+          blo[j] = tb[(kk * 4 + h) * BN + col];
+          bhi[j] = tb[(kk * 4 + 2 + h) * BN + col];
+        }
       }
 #pragma unroll
       for (int i = 0; i < TM; ++i)
@@ -167,12 +192,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a, const
     }
   }
 
-  // epilogue: affine (folded BN or bias) -> leaky -> + residual -> store (x1 or x2-replicated)
-  const int Wop = a.Wo * a.ups + 2;
+  // epilogue: affine (folded BN or bias) -> leaky -> + addend -> store (x1 or x2-replicated)
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int n = n0 + (wn * TN + j) * 32 + lrow;
-    const bool nvalid = n < a.Cout;
+    const bool nvalid = n < a.N;
     float sc = 1.0f, sh = 0.0f;
     if (nvalid) {
       if (a.scale) sc = a.scale[n];
@@ -183,39 +207,89 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a, const
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        const long long oo = out_off[row];
-        if (oo < 0 || !nvalid) continue;
+        const long long op = o_pix[row];
+        if (op < 0 || !nvalid) continue;
         float vv = acc[i][j][r];
         if (a.scale)
           vv = fmaf(vv, sc, sh);
         else if (a.shift)
           vv = vv + sh;
         if (a.leaky) vv = vy_leaky(vv);
-        if (a.res) vv = vv + a.res[res_off[row] + n];
-        float* o = a.out + oo + n;
+        if (a.res) vv = vv + a.res[op * a.r_cs + a.r_co + n];
+        float* o = a.out + op * a.o_cs + a.o_co + n;
         o[0] = vv;
         if (a.ups == 2) {
-          o[a.out_cs] = vv;
-          o[(long long)Wop * a.out_cs] = vv;
-          o[(long long)(Wop + 1) * a.out_cs] = vv;
+          o[a.o_cs] = vv;
+          o[(long long)a.o_Wp * a.o_cs] = vv;
+          o[(long long)(a.o_Wp + 1) * a.o_cs] = vv;
         }
       }
+    }
+  }
+
+  // train-mode BatchNorm: per-tile column sums of the raw accumulators (deterministic: fixed
+  // order inside the tile, tiles are combined in order by the finalize kernel)
+  if (a.stats) {
+    float s1[TN], s2[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      s1[j] = 0.0f;
+      s2[j] = 0.0f;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          const float vv = o_pix[row] >= 0 ? acc[i][j][r] : 0.0f;
+          s1[j] += vv;
+          s2[j] = fmaf(vv, vv, s2[j]);
+        }
+      s1[j] += __shfl_xor(s1[j], 32);
+      s2[j] += __shfl_xor(s2[j], 32);
+    }
+    __syncthreads();  // every wave is past its last LDS tile read
+    float* red = reinterpret_cast<float*>(smem);  // [WM][2][BN]
+    if (h == 0) {
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int col = (wn * TN + j) * 32 + lrow;
+        red[(wm * 2 + 0) * BN + col] = s1[j];
+        red[(wm * 2 + 1) * BN + col] = s2[j];
+      }
+    }
+    __syncthreads();
+    if (tid < BN && n0 + tid < a.N) {
+      float t1 = 0.0f, t2 = 0.0f;
+#pragma unroll
+      for (int w = 0; w < WM; ++w) {
+        t1 += red[(w * 2 + 0) * BN + tid];
+        t2 += red[(w * 2 + 1) * BN + tid];
+      }
+      a.stats[((long long)tile_m * 2 + 0) * a.N + n0 + tid] = t1;
+      a.stats[((long long)tile_m * 2 + 1) * a.N + n0 + tid] = t2;
     }
   }
 #endif  // __HIP_DEVICE_COMPILE__
 }
 
-
 template <int BM, int BN, int WM, int WN>
 static hipError_t launch_cfg(const ConvArgs& a, hipStream_t s) {
-  const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.Cout + BN - 1) / BN;
-  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN>), dim3(tiles_m * tiles_n), dim3(256), 0, s, a, tiles_n);
+  const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + BN - 1) / BN;
+  if (a.dgrad)
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, true>), dim3(tiles_m * tiles_n), dim3(256), 0, s, a,
+                       tiles_n);
+  else
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, false>), dim3(tiles_m * tiles_n), dim3(256), 0, s, a,
+                       tiles_n);
   return hipGetLastError();
 }
 
+int vy_conv_tiles_m(const ConvArgs& a) { return (a.M + 127) / 128; }
+
 hipError_t vy_launch_conv_igemm(const ConvArgs& a, hipStream_t s) {
-  if (a.Cin % 32 != 0 || (a.ksize != 1 && a.ksize != 3) || a.M <= 0) return hipErrorInvalidValue;
-  if (a.Cout <= 32) return launch_cfg<128, 32, 4, 1>(a, s);
-  if (a.Cout <= 64) return launch_cfg<128, 64, 2, 2>(a, s);
+  if (a.Kc % 32 != 0 || a.ntaps < 1 || a.ntaps > 9 || a.M <= 0 || a.N <= 0) return hipErrorInvalidValue;
+  if (a.dgrad && (a.N % 4 != 0)) return hipErrorInvalidValue;
+  if (a.N <= 32) return launch_cfg<128, 32, 4, 1>(a, s);
+  if (a.N <= 64) return launch_cfg<128, 64, 2, 2>(a, s);
   return launch_cfg<128, 128, 2, 2>(a, s);
 }

@@ -6,26 +6,38 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// One launch of the implicit-GEMM conv kernel.  Rows m = (b, y, x) over a logical LH x LW grid;
+// the A row of pixel m for tap t is Kc contiguous floats at the plane position
+// (y*a_s + a_oy + tap_dy[t], x*a_s + a_ox + tap_dx[t]) (padded coordinates).  The same kernel runs
+//   forward      A = input activations, W rows = Cout ([n][k] operand), taps = (kh-p, kw-p)
+//   dgrad        A = dz (gradient of the conv output), W read as [k = cout][n = cin], taps flipped;
+//                stride-2 convs run one launch per input-pixel parity class (o_s = 2)
 struct ConvArgs {
-  const float* in;      // input plane base
-  const float* w;       // weights [Cout][k*k*Cin], K ordered (kh, kw, cin)
-  const float* scale;   // per-Cout, nullable (folded BN scale)
-  const float* shift;   // per-Cout, nullable (folded BN shift, or conv bias when scale == null)
-  const float* res;     // residual plane base, nullable (same H,W as output, ups == 1)
+  const float* in;      // A operand plane base
+  const float* w;       // weights [Cout][taps][Cin]
+  const float* scale;   // per-N, nullable (folded BN scale)
+  const float* shift;   // per-N, nullable (folded BN shift, or conv bias when scale == null)
+  const float* res;     // addend plane (residual / gradient accumulate), nullable; pixel map of `out`
   float* out;           // output plane base
-  int B, Hi, Wi;        // input spatial (unpadded)
-  int in_cs, in_co, Cin;    // input plane channel stride, channel offset of this view, channels
-  int Ho, Wo;           // conv output spatial (before upsample)
-  int out_cs, out_co, Cout;
-  int res_cs, res_co;
-  int ksize, stride;    // 1|3, 1|2 ; padding = ksize/2
-  int leaky;            // LeakyReLU(0.1) after the affine
+  float* stats;         // nullable: per-M-tile column sums [tiles_m][2][N] (train-mode BatchNorm)
+  int B, LH, LW, M;     // M = B*LH*LW
+  int a_Hp, a_Wp, a_cs, a_co, a_s, a_oy, a_ox;
+  int Kc;               // A channels per tap, multiple of 32
+  int ntaps;
+  signed char tap_dy[9], tap_dx[9];
+  unsigned char tap_w[9];   // weight tap index (kh*k + kw) of tap t
+  int w_taps, w_cin, w_cout;  // weight tensor dims
+  int N;                // GEMM columns of this launch
+  int o_Hp, o_Wp, o_cs, o_co, o_s, o_oy, o_ox;
   int ups;              // 1, or 2: nearest x2 replicate on store (layers.py:11-20 fused)
-  int M;                // B*Ho*Wo
+  int r_cs, r_co;
+  int leaky;            // LeakyReLU(0.1) after the affine
+  int dgrad;            // 0: W is the [n][k] operand (forward); 1: W is the [k][n] operand (dgrad)
 };
 
-// 3x3/1x1 implicit-GEMM convolution on v_mfma_f32_32x32x2_f32, Cin % 32 == 0.
+// 3x3/1x1 implicit-GEMM convolution on v_mfma_f32_32x32x2_f32.
 hipError_t vy_launch_conv_igemm(const ConvArgs& a, hipStream_t s);
+int vy_conv_tiles_m(const ConvArgs& a);
 
 // stem: 3x3 stride-1 conv from the caller's NCHW image (Cin = 3) into a plane, fused affine+leaky.
 struct StemArgs {

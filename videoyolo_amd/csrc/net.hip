@@ -293,6 +293,8 @@ struct vy_net {
     return 0;
   }
 
+  // forward launch of conv `c`: reads plane views, writes `out_plane_ptr` (the activation plane, or
+  // the raw-conv "z" plane in training)
   ConvArgs conv_args(const ConvT& c) const {
     ConvArgs a;
     memset(&a, 0, sizeof a);
@@ -309,26 +311,42 @@ struct vy_net {
     }
     a.res = c.res_plane >= 0 ? plane_ptr(c.res_plane) : nullptr;
     a.out = plane_ptr(c.out_plane);
+    a.stats = nullptr;
+    const int Ho = ip.H / c.stride, Wo = ip.W / c.stride;
     a.B = B;
-    a.Hi = ip.H;
-    a.Wi = ip.W;
-    a.in_cs = ip.C;
-    a.in_co = c.in_co;
-    a.Cin = c.cin;
-    a.Ho = ip.H / c.stride;
-    a.Wo = ip.W / c.stride;
-    a.out_cs = op.C;
-    a.out_co = c.out_co;
-    a.Cout = c.cout;
-    if (c.res_plane >= 0) {
-      a.res_cs = planes[c.res_plane].C;
-      a.res_co = c.res_co;
+    a.LH = Ho;
+    a.LW = Wo;
+    a.M = B * Ho * Wo;
+    a.a_Hp = ip.H + 2;
+    a.a_Wp = ip.W + 2;
+    a.a_cs = ip.C;
+    a.a_co = c.in_co;
+    a.a_s = c.stride;
+    a.a_oy = a.a_ox = 1;
+    a.Kc = c.cin;
+    a.ntaps = c.k * c.k;
+    for (int t = 0; t < a.ntaps; ++t) {
+      a.tap_dy[t] = (signed char)(c.k == 3 ? t / 3 - 1 : 0);
+      a.tap_dx[t] = (signed char)(c.k == 3 ? t % 3 - 1 : 0);
+      a.tap_w[t] = (unsigned char)t;
     }
-    a.ksize = c.k;
-    a.stride = c.stride;
-    a.leaky = c.leaky;
+    a.w_taps = c.k * c.k;
+    a.w_cin = c.cin;
+    a.w_cout = c.cout;
+    a.N = c.cout;
+    a.o_Hp = Ho * c.ups + 2;
+    a.o_Wp = Wo * c.ups + 2;
+    a.o_cs = op.C;
+    a.o_co = c.out_co;
+    a.o_s = c.ups;
+    a.o_oy = a.o_ox = 1;
     a.ups = c.ups;
-    a.M = B * a.Ho * a.Wo;
+    if (c.res_plane >= 0) {
+      a.r_cs = planes[c.res_plane].C;
+      a.r_co = c.res_co;
+    }
+    a.leaky = c.leaky;
+    a.dgrad = 0;
     return a;
   }
 
@@ -404,9 +422,9 @@ struct vy_net {
         hook(c.name.c_str(), fl, by, false);
       } else {
         const ConvArgs a = conv_args(c);
-        const double fl = 2.0 * a.M * (double)a.Cout * a.ksize * a.ksize * a.Cin;
-        const double by = 4.0 * ((double)B * a.Hi * a.Wi * a.Cin + (double)a.M * a.Cout * a.ups * a.ups +
-                                 (double)a.Cout * a.ksize * a.ksize * a.Cin + (a.res ? (double)a.M * a.Cout : 0.0));
+        const double fl = 2.0 * a.M * (double)a.N * a.ntaps * a.Kc;
+        const double by = 4.0 * ((double)B * (a.a_Hp - 2) * (a.a_Wp - 2) * a.Kc + (double)a.M * a.N * a.ups * a.ups +
+                                 (double)a.N * a.ntaps * a.Kc + (a.res ? (double)a.M * a.N : 0.0));
         hook(c.name.c_str(), fl, by, true);
         HIP_TRY(vy_launch_conv_igemm(a, s));
         hook(c.name.c_str(), fl, by, false);
