@@ -134,6 +134,71 @@ typedef struct vy_launch_stat {
 int vy_net_profile_infer(vy_net* net, const float* x, float* ids, float* scores, float* bboxes,
                          vy_launch_stat* stats, int32_t* n, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Training step.  Reference call pattern, train_yolov3.py:623-634:
+ *     with autograd.record():
+ *         obj, ctr, scl, cls = net(x, gt_boxes, obj_t, centers_t, scales_t, weights_t, clas_t)
+ *         autograd.backward(obj + ctr + scl + cls)
+ *     trainer.step(batch_size)
+ * The caller owns two more device buffers of vy_net_param_bytes each (gradients, SGD momentum;
+ * same element offsets as the parameter buffer: one contiguous range for the RCCL all-reduce) and a
+ * training workspace (activations, raw conv outputs / their gradients, gradient planes, scratch).
+ * ---------------------------------------------------------------------------------------------- */
+size_t vy_net_train_workspace_bytes(const vy_net* net, int32_t batch, int32_t height, int32_t width);
+/* Binds the training workspace (also serves inference at that shape), the gradient buffer and the
+ * momentum buffer (the caller zero-initialises the momentum once); zeroes the workspace
+ * asynchronously on `stream`. */
+int vy_net_bind_train(vy_net* net, void* dev_ws, size_t bytes, int32_t batch, int32_t height,
+                      int32_t width, void* dev_grads, void* dev_momentum, void* stream);
+
+/* YOLOV3T(ignore_iou_thresh=0.7) (yolo3.py:962) and net._target_generator._label_smooth
+ * (train_yolov3.py:499-500, yolo_target.py:272-278). */
+int vy_net_set_train_options(vy_net* net, float ignore_iou_thresh, int32_t label_smooth);
+
+/* net(x, gt_boxes, *fixed_targets) under autograd.record() — yolo3.py:1126-1187 with BatchNorm on
+ * batch statistics (running stats updated, momentum 0.9), YOLOV3TargetMerger (yolo_target.py:
+ * 226-281) and YOLOV3Loss.  Also computes d(sum of the four losses)/d(raw predictions), so that
+ * vy_net_train_backward only has to walk the network.
+ *   x (B,3,H,W)  gt_boxes (B,M,4) corner px, -1 padded   obj_t (B,N,1)  centers_t/scales_t/weights_t
+ *   (B,N,2)  clas_t (B,N,C) — N anchors in the reference order (stride 32,16,8; cell; anchor)
+ *   losses: device (4,B): obj, center, scale, cls per sample. */
+int vy_net_train_forward(vy_net* net, const float* x, const float* gt_boxes, int32_t M,
+                         const float* obj_t, const float* centers_t, const float* scales_t,
+                         const float* weights_t, const float* clas_t, float* losses, void* stream);
+
+/* autograd.backward(sum_losses) (train_yolov3.py:631): fills the gradient buffer (every trainable
+ * tensor, device layout) from the state left by the last vy_net_train_forward.  `x` is the same
+ * image batch (needed by the stem's weight gradient). */
+int vy_net_train_backward(vy_net* net, const float* x, void* stream);
+
+/* Per-parameter optimizer attributes: Parameter.lr_mult / wd_mult (train_yolov3.py:496-497) and
+ * grad_req = 'null' (enabled = 0; wrappers.py:55-57 freeze_base). */
+int vy_net_param_set_opt(vy_net* net, int32_t i, float lr_mult, float wd_mult, int32_t enabled);
+
+/* trainer.step(batch_size) for Trainer('sgd', {wd, momentum}) (train_yolov3.py:527-530,634):
+ * g = rescale_grad*grad + wd*w ; mom = momentum*mom - lr*g ; w += mom.  rescale_grad = 1/batch_size.
+ * Gradients must already be summed across ranks (all-reduce of the gradient buffer). */
+int vy_net_sgd_step(vy_net* net, float lr, float momentum, float wd, float rescale_grad, void* stream);
+
+/* Gradient of parameter i in the REFERENCE layout to host memory (tests / checkpoints). */
+int vy_net_grad_get(vy_net* net, int32_t i, float* host_dst, void* stream);
+
+/* SyncBatchNorm(num_devices) (train_yolov3.py:352-354).  With world > 1 the BatchNorm layers that
+ * the reference builds with the passed norm_layer — the stem and the five stride-2 convs of
+ * Darknet-53 (three_darknet.py:163-181; the residual blocks hard-code BatchNorm, :193-194, and
+ * wrappers.py:101-103 does not forward norm_layer to YOLOV3T) — call `cb` to sum their [2][C]
+ * double-precision statistics over all ranks, forward and backward.  cb(user, device_ptr, count)
+ * must all-reduce (sum) `count` doubles in place, ordered with the stream passed to the step. */
+typedef int (*vy_allreduce_cb)(void* user, void* dev_ptr, int64_t count);
+int vy_net_set_sync_bn(vy_net* net, int32_t world, vy_allreduce_cb cb, void* user);
+
+/* Bucketed gradient exchange: during vy_net_train_backward `cb(user, elem_offset, elem_count)` is
+ * called each time a contiguous range of the gradient buffer is final (heads first, then Darknet
+ * stages 2, 1, 0), after the kernels producing it were enqueued — the caller records an event and
+ * all-reduces that range on a side stream, overlapping the rest of the backward pass. */
+typedef int (*vy_grad_bucket_cb)(void* user, int64_t elem_offset, int64_t elem_count);
+int vy_net_set_grad_bucket_cb(vy_net* net, vy_grad_bucket_cb cb, void* user);
+
 #ifdef __cplusplus
 }
 #endif

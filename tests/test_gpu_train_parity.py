@@ -1,0 +1,114 @@
+"""-m gpu: one training step of the HIP path (through the C-ABI) against the CPU training oracle:
+the four per-sample losses, every parameter gradient, the BatchNorm running statistics and the
+SGD-updated parameters.  Tolerances: losses 1e-4 (north_star), gradients 2e-3 of each tensor's
+max |g| (fp32 MFMA reductions over up to 10^5 pixels vs the oracle's double accumulation)."""
+import numpy as np
+import pytest
+
+from conftest import frames
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(C, B, S, seed=11, m=3, pad_to=5):
+    from videoyolo_amd import init
+    from oracle import targets_oracle as T
+    from oracle import yolo3_oracle as O
+    params = init.synthetic_params(O.param_shapes(C), seed=seed)
+    x = frames(B, S, seed=5)
+    gt_boxes, gt_ids = T.synthetic_gt(B, S, C, m=m, seed=2, pad_to=pad_to)
+    tg = T.prefetch_targets(C, S, S, gt_boxes, gt_ids)
+    return params, x, gt_boxes, tg
+
+
+def _net(C, params):
+    import videoyolo_amd as vy
+    net = vy.yolo3_darknet53(["c%d" % i for i in range(C)], pretrained_base=False)
+    net.set_parameters(params)
+    net.collect_params().reset_ctx("cuda:0")
+    return net
+
+
+@pytest.mark.parametrize("C,B,S", [(4, 2, 64), (20, 2, 96)])
+def test_train_step_matches_oracle(C, B, S):
+    import videoyolo_amd as vy
+    from videoyolo_amd import autograd
+    from oracle import yolo3_train_oracle as TO
+    params, x, gt_boxes, tg = _setup(C, B, S)
+    orc = TO.OracleYolo3Train(C, dict(params))
+    ref_losses = orc.forward_train(x, gt_boxes, *tg)
+    ref_grads = orc.backward()
+
+    net = _net(C, params)
+    trainer = vy.Trainer(net.collect_params(), 'sgd', {'learning_rate': 1e-3, 'wd': 5e-4, 'momentum': 0.9})
+    with autograd.record():
+        losses = net(x, gt_boxes, *tg)
+        total = losses[0] + losses[1] + losses[2] + losses[3]
+        autograd.backward([total])
+    for got, want in zip(losses, ref_losses):
+        np.testing.assert_allclose(got.cpu().numpy(), want, rtol=1e-4, atol=1e-4)
+    assert float(sum(l.sum() for l in losses)) > 0
+
+    worst = ("", 0.0)
+    for name, want in ref_grads.items():
+        got = net.grad(name)
+        assert got.shape == want.shape
+        err = np.abs(got - want).max() / (np.abs(want).max() + 1e-6)
+        if err > worst[1]:
+            worst = (name, err)
+        assert err < 2e-3, (name, err)
+    print("worst gradient mismatch:", worst)
+
+    # running statistics (momentum 0.9, biased batch variance)
+    for name, want in orc.new_running.items():
+        got = net.collect_params()[name].data()
+        np.testing.assert_allclose(got, want, rtol=1e-4, atol=1e-5)
+
+    # trainer.step(batch_size): mom = 0.9*mom - lr*(g/bs + wd*w); w += mom
+    p_ref = {k: v.copy() for k, v in params.items()}
+    mom = {}
+    TO.sgd_step(p_ref, ref_grads, mom, 1e-3, 0.9, 5e-4, B)
+    trainer.step(B)
+    for name in ("stages.0.0.0.weight", "stages.1.4.body.1.0.weight", "yolo_blocks.1.tip.1.gamma",
+                 "yolo_outputs.2.prediction.bias", "transitions.0.0.weight"):
+        got = net.collect_params()[name].data()
+        np.testing.assert_allclose(got, p_ref[name], rtol=0, atol=2e-6)
+        assert np.abs(got - params[name]).max() > 0
+
+
+def test_train_options_and_inference_after_training():
+    """label smoothing + no_wd / frozen backbone switches, then net(x) in inference mode on the same
+    object (validate() after an epoch, train_yolov3.py:434-441)."""
+    import videoyolo_amd as vy
+    from videoyolo_amd import autograd
+    from oracle import yolo3_train_oracle as TO
+    from oracle import yolo3_oracle as O
+    C, B, S = 3, 2, 64
+    params, x, gt_boxes, tg = _setup(C, B, S, seed=4)
+    orc = TO.OracleYolo3Train(C, dict(params), label_smooth=True)
+    ref_losses = orc.forward_train(x, gt_boxes, *tg)
+    ref_grads = orc.backward()
+    net = _net(C, params)
+    net._target_generator._label_smooth = True
+    for p in net.collect_params('.*beta|.*gamma|.*bias').values():
+        p.wd_mult = 0.0
+    for p in net.collect_params().values():
+        if p.backbone:
+            p.grad_req = 'null'
+    trainer = vy.Trainer(net.collect_params(), 'sgd', {'learning_rate': 1e-2, 'wd': 5e-4, 'momentum': 0.9})
+    with autograd.record():
+        losses = net(x, gt_boxes, *tg)
+        autograd.backward([sum(losses)])
+    for got, want in zip(losses, ref_losses):
+        np.testing.assert_allclose(got.cpu().numpy(), want, rtol=1e-4, atol=1e-4)
+    trainer.step(B)
+    frozen = net.collect_params()["stages.0.3.0.weight"].data()
+    assert np.array_equal(frozen, params["stages.0.3.0.weight"])
+    g = ref_grads["yolo_blocks.0.tip.1.gamma"] / B
+    want = params["yolo_blocks.0.tip.1.gamma"] - 1e-2 * g          # wd_mult = 0
+    np.testing.assert_allclose(net.collect_params()["yolo_blocks.0.tip.1.gamma"].data(), want, atol=2e-6)
+    # inference on the updated parameters == oracle inference on the same parameters
+    newp = {k: p.data() for k, p in net.collect_params().items()}
+    ids, scores, bboxes, keep = [t.cpu().numpy() for t in net(x, return_index=True)]
+    r = O.OracleYolo3(C, newp)(x)
+    assert np.array_equal(keep, r[3]) and np.array_equal(ids, r[0])

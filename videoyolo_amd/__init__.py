@@ -3,5 +3,7 @@ C-ABI, include/vyolo.h) with the model-object surface of HaydenFaulkner/VideoYOL
 ``models.definitions.yolo.wrappers.yolo3_darknet53``."""
 from . import autograd  # noqa: F401
 from .model import YOLOV3, YOLOV3T, BatchNorm, SyncBatchNorm, yolo3_darknet53  # noqa: F401
+from .trainer import Trainer  # noqa: F401
+from . import parallel  # noqa: F401
 
-__all__ = ["yolo3_darknet53", "YOLOV3", "YOLOV3T", "BatchNorm", "SyncBatchNorm", "autograd"]
+__all__ = ["yolo3_darknet53", "YOLOV3", "YOLOV3T", "BatchNorm", "SyncBatchNorm", "autograd", "Trainer", "parallel"]

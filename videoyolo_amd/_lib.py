@@ -54,6 +54,22 @@ SIGNATURES = {
                                             ctypes.POINTER(_i32), _vp]),
 }
 
+ALLREDUCE_CB = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64)
+GRAD_BUCKET_CB = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64)
+
+SIGNATURES.update({
+    "vy_net_train_workspace_bytes": (_sz, [_vp, _i32, _i32, _i32]),
+    "vy_net_bind_train": (ctypes.c_int, [_vp, _vp, _sz, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "vy_net_set_train_options": (ctypes.c_int, [_vp, _f32, _i32]),
+    "vy_net_train_forward": (ctypes.c_int, [_vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "vy_net_train_backward": (ctypes.c_int, [_vp, _vp, _vp]),
+    "vy_net_param_set_opt": (ctypes.c_int, [_vp, _i32, _f32, _f32, _i32]),
+    "vy_net_sgd_step": (ctypes.c_int, [_vp, _f32, _f32, _f32, _f32, _vp]),
+    "vy_net_grad_get": (ctypes.c_int, [_vp, _i32, _vp, _vp]),
+    "vy_net_set_sync_bn": (ctypes.c_int, [_vp, _i32, ALLREDUCE_CB, _vp]),
+    "vy_net_set_grad_bucket_cb": (ctypes.c_int, [_vp, GRAD_BUCKET_CB, _vp]),
+})
+
 _lib = None
 
 

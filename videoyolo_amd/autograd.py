@@ -52,3 +52,26 @@ def train_mode():
 
 def predict_mode():
     return _scope(None, False)
+
+
+# ---- the tape: nets that ran a recorded forward and still owe a backward pass
+def _register(net):
+    s = _get()
+    if not hasattr(s, "tape"):
+        s.tape = []
+    if net not in s.tape:
+        s.tape.append(net)
+
+
+def backward(heads, head_grads=None, retain_graph=False, train_mode=True):
+    """``autograd.backward(sum_losses)`` (train_yolov3.py:631).  The only pattern the reference uses —
+    unit head gradients on the sum of the four loss vectors of each net — is what the recorded
+    forward already prepared; this walks every pending net's backward pass."""
+    if head_grads is not None:
+        raise NotImplementedError("non-unit head gradients are not part of the reference's call pattern")
+    s = _get()
+    tape, s.tape = getattr(s, "tape", []), []
+    if not tape:
+        raise RuntimeError("autograd.backward() without a recorded forward")
+    for net in tape:
+        net.backward()

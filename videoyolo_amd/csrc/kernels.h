@@ -84,3 +84,143 @@ size_t vy_det_scratch_bytes(int B);
 // full tail: decode -> radix select of the top-k valid scores -> sort -> per-class NMS -> outputs
 hipError_t vy_launch_detect(const DetArgs& a, void* scratch, float* ids, float* scores, float* bboxes,
                             int32_t* keep_idx, hipStream_t s);
+
+// =============================================================================================
+// Training kernels (train_kernels.hip, wgrad.hip)
+// =============================================================================================
+// out[c] = sum over t < n_part of partials[t*n_cols + c], accumulated in double in index order
+// (deterministic).  Used for BatchNorm statistics, BN-backward sums, bias gradients.
+hipError_t vy_launch_reduce_partials(const float* partials, int n_part, int n_cols, double* out,
+                                     hipStream_t s);
+
+hipError_t vy_launch_f64_to_f32(const double* src, float* dst, int n, hipStream_t s);
+
+// batch statistics -> normalisation coefficients (mxnet BatchNorm, train mode; layers.py:68)
+struct BnFinalizeArgs {
+  const double* sums;     // [2][C]: sum x, sum x^2 over `count` samples (all ranks when SyncBN)
+  double count;
+  const float* gamma;
+  const float* beta;
+  float* running_mean;    // updated in place: r = momentum*r + (1-momentum)*batch
+  float* running_var;
+  float* scale;           // gamma * invstd
+  float* shift;           // beta - mean*scale
+  float* save_mean;       // for backward
+  float* save_invstd;
+  int C;
+  float eps, momentum;
+};
+hipError_t vy_launch_bn_finalize(const BnFinalizeArgs& a, hipStream_t s);
+
+// a = leaky(fma(z, scale, shift)) (+ res), z plane (B,H+2,W+2,C) -> output view (x1 or x2 replicate)
+struct BnApplyArgs {
+  const float* z;
+  const float* scale;
+  const float* shift;
+  const float* res;       // nullable, pixel map of out
+  float* out;
+  int B, H, W, C;         // z plane: cs == C, co == 0
+  int o_Hp, o_Wp, o_cs, o_co, ups;
+  int r_cs, r_co;
+};
+hipError_t vy_launch_bn_apply(const BnApplyArgs& a, hipStream_t s);
+
+// BatchNorm + LeakyReLU backward.  da is read from a gradient view (x2-replicated outputs are
+// summed over their 2x2 replicas); y = fma(z, scale, shift) decides the leaky branch.
+struct BnBwdArgs {
+  const float* g;         // gradient plane of the cell's output view
+  float* z;               // raw conv output; overwritten with dz by the apply pass
+  const float* scale;
+  const float* shift;
+  const float* save_mean;
+  const float* save_invstd;
+  const float* coef;      // [3][C]: c1 = gamma*invstd, c2 = dbeta/n, c3 = dgamma/n  (apply pass)
+  float* partials;        // [n_chunks][2][C]  (reduce pass)
+  int B, H, W, C;
+  int g_Hp, g_Wp, g_cs, g_co, ups;
+  int chunk;              // pixels per partial chunk
+};
+int vy_bn_bwd_chunks(const BnBwdArgs& a);
+hipError_t vy_launch_bn_bwd_reduce(const BnBwdArgs& a, hipStream_t s);
+struct BnBwdFinalizeArgs {
+  const double* sums;     // [2][C]: sum dy, sum dy*xhat (all ranks when SyncBN)
+  double count;
+  const float* gamma;
+  const float* save_invstd;
+  float* dgamma;          // gradient buffer slots
+  float* dbeta;
+  float* coef;            // [3][C]
+  int C;
+  int local_only;         // SyncBN: dgamma/dbeta stay LOCAL sums (they are all-reduced with the grads);
+  const double* local_sums;
+};
+hipError_t vy_launch_bn_bwd_finalize(const BnBwdFinalizeArgs& a, hipStream_t s);
+hipError_t vy_launch_bn_bwd_apply(const BnBwdArgs& a, hipStream_t s);
+
+// per-channel sums of a plane view over all pixels -> partials [n_chunks][C] (prediction-conv bias grad)
+hipError_t vy_launch_colsum(const float* plane, int B, int H, int W, int cs, int co, int C, int chunk,
+                            float* partials, hipStream_t s);
+int vy_colsum_chunks(int B, int H, int W, int chunk);
+
+// ---- weight gradient: dW[o][tap][cin] = sum_p dz[p][o] * a[p*s + tap][cin]  (split-K slabs)
+struct WgradArgs {
+  const float* dz;        // plane (B, Ho+2, Wo+2, z_cs)
+  const float* a;         // input activation view
+  float* slabs;           // [splits][Cout][taps*Cin]
+  const float* zero;      // >= 512 zero bytes (rows beyond M)
+  int B, Ho, Wo, M;       // M = B*Ho*Wo
+  int z_cs, Cout;
+  int a_Hp, a_Wp, a_cs, a_co, stride;
+  int k, Cin;             // kernel size, input channels (multiple of 32)
+  int splits, k_per_split;  // k_per_split pixels (multiple of 32) per split
+};
+hipError_t vy_launch_wgrad(const WgradArgs& a, hipStream_t s);
+// dst[i] = sum_s slabs[s][i]  (fixed order)
+hipError_t vy_launch_slab_reduce(const float* slabs, int splits, long long n, float* dst, hipStream_t s);
+
+// stem weight gradient (Cin = 3): partials [blocks][32*27] then vy_launch_reduce_partials
+struct StemWgradArgs {
+  const float* x;         // (B,3,H,W) NCHW image
+  const float* dz;        // plane (B,H+2,W+2,32)
+  float* partials;
+  int B, H, W;
+};
+int vy_stem_wgrad_blocks(int B, int H, int W);
+hipError_t vy_launch_stem_wgrad(const StemWgradArgs& a, hipStream_t s);
+
+// stem forward in training: raw conv -> z plane + per-block column sums [blocks][2][32]
+int vy_stem_blocks(int B, int H, int W);
+hipError_t vy_launch_stem_raw(const StemArgs& a, float* partials, hipStream_t s);
+
+// ---- fused targets + loss + d(loss)/d(raw predictions)
+// yolo_target.py:173-205 (dynamic ignore mask), :226-281 (merge), gluoncv YOLOV3Loss (yolo3.py:1187)
+struct LossArgs {
+  HeadView head[3];       // prediction planes (read)
+  float* dpred[3];        // gradient planes, same geometry as head[i].pred (written)
+  const float* gt_boxes;  // (B, M, 4) corner, -1 padded
+  const float* obj_t;     // (B, N, 1)
+  const float* centers_t; // (B, N, 2)
+  const float* scales_t;  // (B, N, 2)
+  const float* weights_t; // (B, N, 2)
+  const float* clas_t;    // (B, N, C)
+  float* partials;        // [blocks_per_image][B][4]
+  int B, C, M, N;
+  float ignore_iou_thresh;
+  int label_smooth;
+};
+int vy_loss_blocks_per_image(int N);
+hipError_t vy_launch_loss(const LossArgs& a, hipStream_t s);
+// losses[l][b] = sum over blocks of partials (fixed order), l = obj, center, scale, cls
+hipError_t vy_launch_loss_reduce(const float* partials, int blocks_per_image, int B, float* losses,
+                                 hipStream_t s);
+
+// ---- SGD with momentum (mx.optimizer.SGD via gluon.Trainer.step, train_yolov3.py:527-530,634)
+struct SgdSeg {
+  int64_t off, size;      // element range in the flat parameter / gradient / momentum buffers
+  float lr_mult, wd_mult;
+  int32_t enabled, pad;
+};
+hipError_t vy_launch_sgd(float* params, const float* grads, float* mom, const SgdSeg* segs_dev,
+                         const int32_t* chunk_seg_dev, int n_chunks, float lr, float momentum, float wd,
+                         float rescale, hipStream_t s);
+#define VY_SGD_CHUNK 4096

@@ -1,0 +1,427 @@
+// net_internal.h — the vy_net object shared by net.hip (graph, planner, inference C-ABI) and
+// train.hip (training planner and C-ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/vyolo.h"
+#include "kernels.h"
+
+// error channel (defined in net.hip)
+int vy_fail(int code, const char* fmt, ...);
+#define fail vy_fail
+
+#define HIP_TRY(expr)                                                                  \
+  do {                                                                                 \
+    hipError_t e_ = (expr);                                                            \
+    if (e_ != hipSuccess) return fail(VY_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+  } while (0)
+
+struct ParamT {
+  vy_param_info info;
+};
+
+struct PlaneT {
+  int C = 0;         // channel stride
+  int div = 1;       // spatial = input / div
+  size_t off = 0;    // float offset in workspace (set by plan)
+  int H = 0, W = 0;  // set by plan
+};
+
+struct ConvT {
+  std::string name;      // structural prefix of the cell, e.g. "stages.0.2.body.1"
+  int in_plane, in_co, cin;
+  int out_plane, out_co, cout;
+  int k, stride, leaky, ups;
+  int res_plane, res_co;          // -1: none
+  int p_weight;                   // param indices
+  int p_gamma, p_beta, p_mean, p_var;  // -1 for the prediction convs
+  int p_bias;                     // -1 for cells
+  int64_t scale_off, shift_off;   // folded BN scratch (element offsets), -1 if none
+  int is_stem;
+};
+
+static const int kAnchors[3][6] = {{10, 13, 16, 30, 33, 23}, {30, 61, 62, 45, 59, 119}, {116, 90, 156, 198, 373, 326}};
+static const int kStrides[3] = {8, 16, 32};  // wrappers.py:80-84
+
+struct VyTrain;
+void vy_train_free(struct vy_net* net);
+
+struct vy_net {
+  int num_class = 0;
+  float nms_thresh = 0.45f;  // YOLOV3T.__init__ defaults, yolo3.py:959-963
+  int nms_topk = 400, post_nms = 100;
+  std::vector<ParamT> params;
+  std::vector<PlaneT> planes;
+  std::vector<ConvT> convs;
+  int head_plane[3] = {-1, -1, -1};  // prediction conv outputs, order stride 32,16,8
+  int64_t param_elems = 0;           // tensors + scratch
+  int64_t tensor_elems = 0;
+  std::vector<FoldDesc> folds;
+  // bound state
+  float* dev_params = nullptr;
+  unsigned char* dev_ws = nullptr;
+  size_t ws_bytes = 0;
+  int B = 0, H = 0, W = 0;
+  size_t fold_desc_off = 0, det_scratch_off = 0, planes_off = 0;  // byte offsets in workspace
+  bool fold_uploaded = false;
+  struct VyTrain* train = nullptr;  // training planner state, owned by train.hip
+
+  int add_param(const std::string& name, int kind, int ndim, const int* shape, int trainable, int backbone) {
+    ParamT p;
+    memset(&p.info, 0, sizeof p.info);
+    snprintf(p.info.name, sizeof p.info.name, "%s", name.c_str());
+    p.info.kind = kind;
+    p.info.ndim = ndim;
+    int64_t sz = 1;
+    for (int i = 0; i < ndim; ++i) {
+      p.info.shape[i] = shape[i];
+      sz *= shape[i];
+    }
+    p.info.size = sz;
+    p.info.offset = param_elems;
+    p.info.trainable = trainable;
+    p.info.backbone = backbone;
+    param_elems += (sz + 63) & ~(int64_t)63;  // 256-B aligned tensors
+    params.push_back(p);
+    return (int)params.size() - 1;
+  }
+
+  int add_plane(int C, int div) {
+    PlaneT p;
+    p.C = C;
+    p.div = div;
+    planes.push_back(p);
+    return (int)planes.size() - 1;
+  }
+
+  // `_conv2d` cell (layers.py:63-70) or a bare prediction conv (yolo3.py:62) when bn == false
+  int add_conv(const std::string& name, int in_plane, int in_co, int cin, int out_plane, int out_co, int cout,
+               int k, int stride, bool bn, int backbone, int res_plane = -1, int res_co = 0, int ups = 1) {
+    ConvT c;
+    c.name = name;
+    c.in_plane = in_plane;
+    c.in_co = in_co;
+    c.cin = cin;
+    c.out_plane = out_plane;
+    c.out_co = out_co;
+    c.cout = cout;
+    c.k = k;
+    c.stride = stride;
+    c.leaky = bn ? 1 : 0;
+    c.ups = ups;
+    c.res_plane = res_plane;
+    c.res_co = res_co;
+    c.is_stem = (cin == 3);
+    c.p_gamma = c.p_beta = c.p_mean = c.p_var = c.p_bias = -1;
+    c.scale_off = c.shift_off = -1;
+    const int wshape[4] = {cout, cin, k, k};
+    const int cshape[1] = {cout};
+    if (bn) {
+      c.p_weight = add_param(name + ".0.weight", VY_P_WEIGHT, 4, wshape, 1, backbone);
+      c.p_gamma = add_param(name + ".1.gamma", VY_P_GAMMA, 1, cshape, 1, backbone);
+      c.p_beta = add_param(name + ".1.beta", VY_P_BETA, 1, cshape, 1, backbone);
+      c.p_mean = add_param(name + ".1.running_mean", VY_P_RUNNING_MEAN, 1, cshape, 0, backbone);
+      c.p_var = add_param(name + ".1.running_var", VY_P_RUNNING_VAR, 1, cshape, 0, backbone);
+    } else {
+      c.p_weight = add_param(name + ".weight", VY_P_WEIGHT, 4, wshape, 1, backbone);
+      c.p_bias = add_param(name + ".bias", VY_P_BIAS, 1, cshape, 1, backbone);
+    }
+    convs.push_back(c);
+    return (int)convs.size() - 1;
+  }
+
+  void build() {
+    char nm[128];
+    const int layers[5] = {1, 2, 8, 8, 4};
+    const int chans[6] = {32, 64, 128, 256, 512, 1024};
+    const int C = num_class;
+    const int npred = 3 * (5 + C);
+    // concat planes of the two shallower heads: [upsampled transition | backbone route]
+    const int cat1 = add_plane(256 + 512, 16);  // yolo3.py:1177 at stride 16
+    const int cat2 = add_plane(128 + 256, 8);   // ... at stride 8
+    // ---- Darknet-53 features (three_darknet.py:162-195), named by stage slice (wrappers.py:58)
+    int feat = 0;  // index into features[]
+    auto feat_name = [&](int f) {
+      int si = f < 15 ? 0 : (f < 24 ? 1 : 2);
+      int j = f - (si == 0 ? 0 : (si == 1 ? 15 : 24));
+      snprintf(nm, sizeof nm, "stages.%d.%d", si, j);
+      return std::string(nm);
+    };
+    int cur = add_plane(32, 1), cur_co = 0;
+    add_conv(feat_name(feat++), -1, 0, 3, cur, 0, 32, 3, 1, true, 1);
+    int div = 1;
+    for (int st = 0; st < 5; ++st) {
+      const int ch = chans[st + 1];
+      div *= 2;
+      int nxt = add_plane(ch, div);
+      add_conv(feat_name(feat++), cur, cur_co, chans[st], nxt, 0, ch, 3, 2, true, 1);
+      cur = nxt;
+      cur_co = 0;
+      for (int bi = 0; bi < layers[st]; ++bi) {
+        const std::string pre = feat_name(feat++);
+        const int mid = add_plane(ch / 2, div);
+        add_conv(pre + ".body.0", cur, cur_co, ch, mid, 0, ch / 2, 1, 1, true, 1);
+        // the last block of stages 0 and 1 (features[14], features[23]) writes the route straight
+        // into its concat plane
+        int outp, outco = 0;
+        if (feat - 1 == 14) {
+          outp = cat2;
+          outco = 128;
+        } else if (feat - 1 == 23) {
+          outp = cat1;
+          outco = 256;
+        } else {
+          outp = add_plane(ch, div);
+        }
+        add_conv(pre + ".body.1", mid, 0, ch / 2, outp, outco, ch, 3, 1, true, 1, cur, cur_co);
+        cur = outp;
+        cur_co = outco;
+      }
+    }
+    // ---- heads, deep -> shallow (yolo3.py:1013-1054, 1126-1177)
+    const int hch[3] = {512, 256, 128};
+    const int hdiv[3] = {32, 16, 8};
+    int x = cur, x_co = cur_co, x_c = 1024;
+    for (int i = 0; i < 3; ++i) {
+      const int ch = hch[i], dv = hdiv[i];
+      for (int j = 0; j < 5; ++j) {
+        snprintf(nm, sizeof nm, "yolo_blocks.%d.body.%d", i, j);
+        const int oc = (j % 2 == 0) ? ch : ch * 2;
+        const int op = add_plane(oc, dv);
+        add_conv(nm, x, x_co, x_c, op, 0, oc, (j % 2 == 0) ? 1 : 3, 1, true, 0);
+        x = op;
+        x_co = 0;
+        x_c = oc;
+      }
+      const int route = x;
+      snprintf(nm, sizeof nm, "yolo_blocks.%d.tip", i);
+      const int tip = add_plane(ch * 2, dv);
+      add_conv(nm, route, 0, ch, tip, 0, ch * 2, 3, 1, true, 0);
+      snprintf(nm, sizeof nm, "yolo_outputs.%d.prediction", i);
+      // channel stride padded to 32 so the plane can be the A operand of the prediction conv's dgrad
+      head_plane[i] = add_plane((npred + 31) & ~31, dv);
+      add_conv(nm, tip, 0, ch * 2, head_plane[i], 0, npred, 1, 1, false, 0);
+      if (i == 2) break;
+      // transition 1x1 (c -> c/2) stored x2-replicated into channels [0, c/2) of the concat plane
+      snprintf(nm, sizeof nm, "transitions.%d", i);
+      const int cat = (i == 0) ? cat1 : cat2;
+      add_conv(nm, route, 0, ch, cat, 0, ch / 2, 1, 1, true, 0, -1, 0, 2);
+      x = cat;
+      x_co = 0;
+      x_c = planes[cat].C;
+    }
+    tensor_elems = param_elems;
+    // folded-BN scratch behind the tensors
+    for (auto& c : convs) {
+      if (c.p_gamma < 0) continue;
+      c.scale_off = param_elems;
+      param_elems += (c.cout + 63) & ~63;
+      c.shift_off = param_elems;
+      param_elems += (c.cout + 63) & ~63;
+      FoldDesc f;
+      f.gamma = params[c.p_gamma].info.offset;
+      f.beta = params[c.p_beta].info.offset;
+      f.mean = params[c.p_mean].info.offset;
+      f.var = params[c.p_var].info.offset;
+      f.scale = c.scale_off;
+      f.shift = c.shift_off;
+      f.C = c.cout;
+      f.pad = 0;
+      folds.push_back(f);
+    }
+  }
+
+  // ---- planning
+  static size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
+
+  size_t plan(int b, int h, int w, bool commit) {
+    size_t off = 0;
+    const size_t fold_off = off;
+    off += al(sizeof(FoldDesc) * folds.size());
+    const size_t det_off = off;
+    off += al(vy_det_scratch_bytes(b));
+    const size_t pl_off = off;
+    size_t fl = 0;
+    for (auto& p : planes) {
+      const int ph = h / p.div, pw = w / p.div;
+      if (commit) {
+        p.H = ph;
+        p.W = pw;
+        p.off = fl;
+      }
+      fl += ((size_t)b * (ph + 2) * (pw + 2) * p.C + 63) & ~(size_t)63;
+    }
+    off += fl * sizeof(float);
+    if (commit) {
+      fold_desc_off = fold_off;
+      det_scratch_off = det_off;
+      planes_off = pl_off;
+      B = b;
+      H = h;
+      W = w;
+    }
+    return off;
+  }
+
+  float* plane_ptr(int i) const { return reinterpret_cast<float*>(dev_ws + planes_off) + planes[i].off; }
+
+  int check_ready() const {
+    if (!dev_params) return fail(VY_ERR_STATE, "parameters not bound (vy_net_bind_params)");
+    if (!dev_ws) return fail(VY_ERR_STATE, "workspace not bound (vy_net_bind_workspace)");
+    return 0;
+  }
+
+  // forward launch of conv `c`: reads plane views, writes `out_plane_ptr` (the activation plane, or
+  // the raw-conv "z" plane in training)
+  ConvArgs conv_args(const ConvT& c) const {
+    ConvArgs a;
+    memset(&a, 0, sizeof a);
+    const PlaneT& ip = planes[c.in_plane];
+    const PlaneT& op = planes[c.out_plane];
+    a.in = plane_ptr(c.in_plane);
+    a.w = dev_params + params[c.p_weight].info.offset;
+    if (c.p_gamma >= 0) {
+      a.scale = dev_params + c.scale_off;
+      a.shift = dev_params + c.shift_off;
+    } else {
+      a.scale = nullptr;
+      a.shift = dev_params + params[c.p_bias].info.offset;
+    }
+    a.res = c.res_plane >= 0 ? plane_ptr(c.res_plane) : nullptr;
+    a.out = plane_ptr(c.out_plane);
+    a.stats = nullptr;
+    const int Ho = ip.H / c.stride, Wo = ip.W / c.stride;
+    a.B = B;
+    a.LH = Ho;
+    a.LW = Wo;
+    a.M = B * Ho * Wo;
+    a.a_Hp = ip.H + 2;
+    a.a_Wp = ip.W + 2;
+    a.a_cs = ip.C;
+    a.a_co = c.in_co;
+    a.a_s = c.stride;
+    a.a_oy = a.a_ox = 1;
+    a.Kc = c.cin;
+    a.ntaps = c.k * c.k;
+    for (int t = 0; t < a.ntaps; ++t) {
+      a.tap_dy[t] = (signed char)(c.k == 3 ? t / 3 - 1 : 0);
+      a.tap_dx[t] = (signed char)(c.k == 3 ? t % 3 - 1 : 0);
+      a.tap_w[t] = (unsigned char)t;
+    }
+    a.w_taps = c.k * c.k;
+    a.w_cin = c.cin;
+    a.w_cout = c.cout;
+    a.N = c.cout;
+    a.o_Hp = Ho * c.ups + 2;
+    a.o_Wp = Wo * c.ups + 2;
+    a.o_cs = op.C;
+    a.o_co = c.out_co;
+    a.o_s = c.ups;
+    a.o_oy = a.o_ox = 1;
+    a.ups = c.ups;
+    if (c.res_plane >= 0) {
+      a.r_cs = planes[c.res_plane].C;
+      a.r_co = c.res_co;
+    }
+    a.leaky = c.leaky;
+    a.dgrad = 0;
+    return a;
+  }
+
+  DetArgs det_args() const {
+    DetArgs d;
+    memset(&d, 0, sizeof d);
+    int base = 0;
+    for (int i = 0; i < 3; ++i) {
+      const PlaneT& p = planes[head_plane[i]];
+      HeadView& hv = d.head[i];
+      hv.pred = plane_ptr(head_plane[i]);
+      hv.H = p.H;
+      hv.W = p.W;
+      hv.cs = p.C;
+      hv.co = 0;
+      hv.stride = (float)kStrides[2 - i];  // anchors/strides used in reverse order, yolo3.py:1013
+      for (int a = 0; a < 3; ++a) {
+        hv.aw[a] = (float)kAnchors[2 - i][2 * a];
+        hv.ah[a] = (float)kAnchors[2 - i][2 * a + 1];
+      }
+      hv.cand_base = base;
+      base += num_class * p.H * p.W * 3;
+    }
+    d.B = B;
+    d.C = num_class;
+    d.n_cand = base;
+    d.valid_thresh = 0.01f;  // yolo3.py:1199
+    d.nms_thresh = nms_thresh;
+    d.topk = nms_topk;
+    d.post_nms = post_nms;
+    d.do_nms = 1;
+    return d;
+  }
+
+  // launches of one inference forward; `hook` (optional) is called around every launch
+  template <typename Hook>
+  int forward(const float* x, float* ids, float* scores, float* bboxes, int32_t* keep_idx, hipStream_t s,
+              Hook&& hook) {
+    if (int rc = check_ready()) return rc;
+    if (!(nms_thresh > 0.f && nms_thresh < 1.f))
+      return fail(VY_ERR_UNSUPPORTED,
+                  "nms_thresh outside (0,1) returns the un-suppressed (B, N*C, 6) tensor in the reference "
+                  "(yolo3.py:1197); not provided by this path");
+    if (nms_topk <= 0 || nms_topk > VY_MAX_TOPK)
+      return fail(VY_ERR_UNSUPPORTED, "nms_topk must be in [1, %d] (got %d)", VY_MAX_TOPK, nms_topk);
+    FoldDesc* fd = reinterpret_cast<FoldDesc*>(dev_ws + fold_desc_off);
+    if (!fold_uploaded) {
+      HIP_TRY(hipMemcpyAsync(fd, folds.data(), sizeof(FoldDesc) * folds.size(), hipMemcpyHostToDevice, s));
+      HIP_TRY(hipStreamSynchronize(s));  // `folds` is pageable host memory; one-time
+      fold_uploaded = true;
+    }
+    hook("bn_fold", 0.0, 0.0, true);
+    HIP_TRY(vy_launch_bn_fold(dev_params, fd, (int)folds.size(), 1024, 1e-5f, s));
+    hook("bn_fold", 0.0, 0.0, false);
+    for (const ConvT& c : convs) {
+      if (c.is_stem) {
+        StemArgs a;
+        a.x = x;
+        a.w = dev_params + params[c.p_weight].info.offset;
+        a.scale = dev_params + c.scale_off;
+        a.shift = dev_params + c.shift_off;
+        a.out = plane_ptr(c.out_plane);
+        a.B = B;
+        a.H = H;
+        a.W = W;
+        a.Cout = c.cout;
+        a.out_cs = planes[c.out_plane].C;
+        a.out_co = c.out_co;
+        const double fl = 2.0 * B * H * W * 27.0 * c.cout;
+        const double by = 4.0 * B * H * W * (3.0 + c.cout);
+        hook(c.name.c_str(), fl, by, true);
+        HIP_TRY(vy_launch_stem(a, s));
+        hook(c.name.c_str(), fl, by, false);
+      } else {
+        const ConvArgs a = conv_args(c);
+        const double fl = 2.0 * a.M * (double)a.N * a.ntaps * a.Kc;
+        const double by = 4.0 * ((double)B * (a.a_Hp - 2) * (a.a_Wp - 2) * a.Kc + (double)a.M * a.N * a.ups * a.ups +
+                                 (double)a.N * a.ntaps * a.Kc + (a.res ? (double)a.M * a.N : 0.0));
+        hook(c.name.c_str(), fl, by, true);
+        HIP_TRY(vy_launch_conv_igemm(a, s));
+        hook(c.name.c_str(), fl, by, false);
+      }
+    }
+    const DetArgs d = det_args();
+    double dby = 0;
+    for (int i = 0; i < 3; ++i) dby += 4.0 * B * d.head[i].H * d.head[i].W * d.head[i].cs;
+    hook("decode_nms", 0.0, dby, true);
+    HIP_TRY(vy_launch_detect(d, dev_ws + det_scratch_off, ids, scores, bboxes, keep_idx, s));
+    hook("decode_nms", 0.0, dby, false);
+    return 0;
+  }
+};
+

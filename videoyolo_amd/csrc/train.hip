@@ -1,0 +1,760 @@
+// train.hip — host side of the training step: plans the extra planes (raw conv outputs z / their
+// gradients dz, gradient planes g), builds the forward-train and backward launch sequences from the
+// same conv list the inference path uses, and implements the training C-ABI of include/vyolo.h.
+//
+// Forward (recording), per `_conv2d` cell (layers.py:63-70 under autograd.record()):
+//   conv (raw, + per-tile channel sums) -> reduce partials -> [SyncBN all-reduce] -> finalize
+//   (mean/var -> scale/shift, running stats) -> apply (BN affine + leaky [+ residual] [x2 replicate])
+// then the prediction convs, then the fused target-merge + loss + d(loss)/d(pred) kernel.
+// Backward, cells in reverse order:
+//   BN/leaky backward reduce -> [all-reduce] -> finalize (dgamma, dbeta, coefficients) -> apply (dz
+//   overwrites z) -> wgrad (split-K slabs + ordered reduce) -> dgrad into the input's gradient plane
+//   (overwrite, or accumulate when the plane already holds another consumer's contribution, plus
+//   the skip connection's gradient as an addend).
+#include "net_internal.h"
+
+namespace {
+
+struct ZPlane {
+  int C = 0;        // channel stride (Cout padded to 4; 0 = none)
+  size_t off = 0;   // float offset in the z region
+  int H = 0, W = 0;
+};
+
+struct BwdDgrad {
+  ConvArgs a[4];
+  int n = 0;
+};
+
+}  // namespace
+
+struct VyTrain {
+  int B = 0, H = 0, W = 0;
+  float* grads = nullptr;
+  float* mom = nullptr;
+  float ignore_iou = 0.7f;
+  int label_smooth = 0;
+  // regions (byte offsets in the workspace)
+  size_t g_off = 0, z_off = 0, save_off = 0, coef_off = 0, sums_off = 0, part_off = 0, slab_off = 0;
+  size_t loss_part_off = 0, loss_off = 0, zero_off = 0, seg_off = 0, chunk_off = 0, total = 0;
+  size_t part_floats = 0, slab_floats = 0;
+  std::vector<ZPlane> z;               // per conv
+  std::vector<size_t> save_idx;        // per conv: float offset of [2][C] saved mean/invstd
+  std::vector<int> splits, kps;        // per conv wgrad split-K
+  std::vector<SgdSeg> segs;
+  std::vector<int32_t> chunk_seg;
+  bool seg_uploaded = false;
+  std::vector<float> lr_mult, wd_mult;
+  std::vector<int> enabled;
+  // SyncBN
+  int world = 1;
+  vy_allreduce_cb ar_cb = nullptr;
+  void* ar_user = nullptr;
+  vy_grad_bucket_cb gb_cb = nullptr;
+  void* gb_user = nullptr;
+  bool forward_done = false;
+  int M = 0;
+};
+
+void vy_train_free(vy_net* net) {
+  delete net->train;
+  net->train = nullptr;
+}
+
+namespace {
+
+size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+bool is_sync_layer(const ConvT& c) {
+  // the layers Darknet3D builds with the passed norm_layer: the stem and the stride-2 convs
+  // (three_darknet.py:163-181); every other BatchNorm in the model is a plain per-device one
+  return c.p_gamma >= 0 && c.name.rfind("stages.", 0) == 0 && c.name.find(".body.") == std::string::npos;
+}
+
+VyTrain* get_train(vy_net* net) {
+  if (!net->train) {
+    net->train = new VyTrain();
+    VyTrain* t = net->train;
+    t->lr_mult.assign(net->params.size(), 1.0f);
+    t->wd_mult.assign(net->params.size(), 1.0f);
+    t->enabled.resize(net->params.size());
+    for (size_t i = 0; i < net->params.size(); ++i) t->enabled[i] = net->params[i].info.trainable;
+  }
+  return net->train;
+}
+
+// plan the training regions behind the inference workspace
+size_t train_plan(vy_net* net, int b, int h, int w, bool commit) {
+  VyTrain* t = get_train(net);
+  size_t off = al256(net->plan(b, h, w, commit));
+  // gradient planes mirror the activation planes
+  size_t gfl = 0;
+  for (auto& p : net->planes) gfl += ((size_t)b * (h / p.div + 2) * (w / p.div + 2) * p.C + 63) & ~(size_t)63;
+  const size_t g_off = off;
+  off += al256(gfl * sizeof(float));
+  // z planes: one per BN conv
+  std::vector<ZPlane> z(net->convs.size());
+  std::vector<size_t> save(net->convs.size(), 0);
+  std::vector<int> splits(net->convs.size(), 1), kps(net->convs.size(), 32);
+  size_t zfl = 0, sfl = 0, part = 0, slab = 0;
+  for (size_t i = 0; i < net->convs.size(); ++i) {
+    const ConvT& c = net->convs[i];
+    const int div_in = c.is_stem ? 1 : net->planes[c.in_plane].div;
+    const int Ho = h / div_in / c.stride, Wo = w / div_in / c.stride;
+    const long long M = (long long)b * Ho * Wo;
+    if (c.p_gamma >= 0) {
+      z[i].C = c.cout;
+      z[i].H = Ho;
+      z[i].W = Wo;
+      z[i].off = zfl;
+      zfl += ((size_t)b * (Ho + 2) * (Wo + 2) * c.cout + 63) & ~(size_t)63;
+      save[i] = sfl;
+      sfl += 2 * (size_t)((c.cout + 63) & ~63);
+      // partials: forward stats, backward sums
+      const size_t tiles_m = (size_t)((M + 127) / 128);
+      size_t pf = c.is_stem ? (size_t)vy_stem_blocks(b, h, w) * 64 : tiles_m * 2 * c.cout;
+      const size_t chunks = (size_t)((M + 2047) / 2048);
+      if (chunks * 2 * c.cout > pf) pf = chunks * 2 * c.cout;
+      if (c.is_stem) {
+        const size_t sw = (size_t)vy_stem_wgrad_blocks(b, h, w) * 864;
+        if (sw > pf) pf = sw;
+      }
+      if (pf > part) part = pf;
+    } else {
+      const size_t chunks = (size_t)((M + 2047) / 2048);
+      if (chunks * c.cout > part) part = chunks * c.cout;
+    }
+    if (!c.is_stem) {
+      const int Ntot = c.k * c.k * c.cin;
+      const int tiles = ((c.cout + 127) / 128) * ((Ntot + 127) / 128);
+      long long sp = (1024 + tiles - 1) / tiles;
+      const long long maxsp = (M + 255) / 256;
+      if (sp > maxsp) sp = maxsp;
+      if (sp < 1) sp = 1;
+      long long k = ((M + sp - 1) / sp + 31) / 32 * 32;
+      sp = (M + k - 1) / k;
+      splits[i] = (int)sp;
+      kps[i] = (int)k;
+      const size_t sl = (size_t)sp * c.cout * Ntot;
+      if (sl > slab) slab = sl;
+    }
+  }
+  const size_t z_off = off;
+  off += al256(zfl * sizeof(float));
+  const size_t save_off = off;
+  off += al256(sfl * sizeof(float));
+  const size_t coef_off = off;
+  off += al256(3 * 1024 * sizeof(float));
+  const size_t sums_off = off;
+  off += al256(2 * 2 * 1024 * sizeof(double));  // [global | local] x [2][C]
+  const size_t part_off = off;
+  off += al256(part * sizeof(float));
+  const size_t slab_off = off;
+  off += al256(slab * sizeof(float));
+  int N = 0;
+  for (int i = 0; i < 3; ++i) {
+    const int dv = net->planes[net->head_plane[i]].div;
+    N += 3 * (h / dv) * (w / dv);
+  }
+  const size_t loss_part_off = off;
+  off += al256((size_t)vy_loss_blocks_per_image(N) * b * 4 * sizeof(float));
+  const size_t loss_off = off;
+  off += al256((size_t)4 * b * sizeof(float));
+  const size_t zero_off = off;
+  off += 1024;
+  // SGD segment tables
+  std::vector<SgdSeg> segs;
+  std::vector<int32_t> chunk_seg;
+  for (size_t i = 0; i < net->params.size(); ++i) {
+    const vy_param_info& pi = net->params[i].info;
+    SgdSeg sg;
+    sg.off = pi.offset;
+    sg.size = pi.size;
+    sg.lr_mult = t->lr_mult[i];
+    sg.wd_mult = t->wd_mult[i];
+    sg.enabled = (pi.trainable && t->enabled[i]) ? 1 : 0;
+    sg.pad = 0;
+    if (!pi.trainable) continue;
+    const int32_t si = (int32_t)segs.size();
+    segs.push_back(sg);
+    const int nch = (int)((pi.size + VY_SGD_CHUNK - 1) / VY_SGD_CHUNK);
+    for (int c = 0; c < nch; ++c) {
+      chunk_seg.push_back(si);
+      chunk_seg.push_back(c);
+    }
+  }
+  const size_t seg_off = off;
+  off += al256(segs.size() * sizeof(SgdSeg));
+  const size_t chunk_off = off;
+  off += al256(chunk_seg.size() * sizeof(int32_t));
+  if (commit) {
+    t->B = b;
+    t->H = h;
+    t->W = w;
+    t->g_off = g_off;
+    t->z_off = z_off;
+    t->save_off = save_off;
+    t->coef_off = coef_off;
+    t->sums_off = sums_off;
+    t->part_off = part_off;
+    t->slab_off = slab_off;
+    t->loss_part_off = loss_part_off;
+    t->loss_off = loss_off;
+    t->zero_off = zero_off;
+    t->seg_off = seg_off;
+    t->chunk_off = chunk_off;
+    t->part_floats = part;
+    t->slab_floats = slab;
+    t->z = z;
+    t->save_idx = save;
+    t->splits = splits;
+    t->kps = kps;
+    t->segs = segs;
+    t->chunk_seg = chunk_seg;
+    t->seg_uploaded = false;
+    t->total = off;
+  }
+  return off;
+}
+
+struct TrainCtx {
+  vy_net* net;
+  VyTrain* t;
+  hipStream_t s;
+  float* gplane(int i) const { return reinterpret_cast<float*>(net->dev_ws + t->g_off) + net->planes[i].off; }
+  float* zplane(int ci) const { return reinterpret_cast<float*>(net->dev_ws + t->z_off) + t->z[ci].off; }
+  float* save(int ci) const { return reinterpret_cast<float*>(net->dev_ws + t->save_off) + t->save_idx[ci]; }
+  float* coef() const { return reinterpret_cast<float*>(net->dev_ws + t->coef_off); }
+  double* sums_global() const { return reinterpret_cast<double*>(net->dev_ws + t->sums_off); }
+  double* sums_local() const { return sums_global() + 2 * 1024; }
+  float* partials() const { return reinterpret_cast<float*>(net->dev_ws + t->part_off); }
+  float* slabs() const { return reinterpret_cast<float*>(net->dev_ws + t->slab_off); }
+  const float* zero() const { return reinterpret_cast<const float*>(net->dev_ws + t->zero_off); }
+  float* grad_of(int pidx) const { return t->grads + net->params[pidx].info.offset; }
+};
+
+// sums_local -> sums_global (+ all-reduce over ranks for the SyncBN layers)
+int combine_sums(const TrainCtx& c, const ConvT& cv, int n_cols, double* count) {
+  HIP_TRY(hipMemcpyAsync(c.sums_global(), c.sums_local(), sizeof(double) * n_cols, hipMemcpyDeviceToDevice, c.s));
+  if (c.t->world > 1 && is_sync_layer(cv)) {
+    if (!c.t->ar_cb) return fail(VY_ERR_STATE, "SyncBN world > 1 without an all-reduce callback");
+    if (int rc = c.t->ar_cb(c.t->ar_user, c.sums_global(), n_cols))
+      return fail(VY_ERR_STATE, "all-reduce callback failed (%d)", rc);
+    *count *= c.t->world;
+  }
+  return 0;
+}
+
+int forward_train(const TrainCtx& c, const float* x) {
+  vy_net* net = c.net;
+  const int B = net->B;
+  for (size_t ci = 0; ci < net->convs.size(); ++ci) {
+    const ConvT& cv = net->convs[ci];
+    if (cv.p_gamma < 0) {  // prediction conv: bias, no BN
+      const ConvArgs a = net->conv_args(cv);
+      HIP_TRY(vy_launch_conv_igemm(a, c.s));
+      continue;
+    }
+    const ZPlane& zp = c.t->z[ci];
+    int n_part;
+    if (cv.is_stem) {
+      StemArgs a;
+      a.x = x;
+      a.w = net->dev_params + net->params[cv.p_weight].info.offset;
+      a.scale = a.shift = nullptr;
+      a.out = c.zplane((int)ci);
+      a.B = B;
+      a.H = net->H;
+      a.W = net->W;
+      a.Cout = cv.cout;
+      a.out_cs = zp.C;
+      a.out_co = 0;
+      HIP_TRY(vy_launch_stem_raw(a, c.partials(), c.s));
+      n_part = vy_stem_blocks(B, net->H, net->W);
+    } else {
+      ConvArgs a = net->conv_args(cv);
+      a.scale = a.shift = a.res = nullptr;
+      a.leaky = 0;
+      a.out = c.zplane((int)ci);
+      a.o_Hp = zp.H + 2;
+      a.o_Wp = zp.W + 2;
+      a.o_cs = zp.C;
+      a.o_co = 0;
+      a.o_s = 1;
+      a.ups = 1;
+      a.stats = c.partials();
+      HIP_TRY(vy_launch_conv_igemm(a, c.s));
+      n_part = vy_conv_tiles_m(a);
+    }
+    const int C = cv.cout;
+    HIP_TRY(vy_launch_reduce_partials(c.partials(), n_part, 2 * C, c.sums_local(), c.s));
+    double count = (double)B * zp.H * zp.W;
+    if (int rc = combine_sums(c, cv, 2 * C, &count)) return rc;
+    BnFinalizeArgs f;
+    f.sums = c.sums_global();
+    f.count = count;
+    f.gamma = net->dev_params + net->params[cv.p_gamma].info.offset;
+    f.beta = net->dev_params + net->params[cv.p_beta].info.offset;
+    f.running_mean = net->dev_params + net->params[cv.p_mean].info.offset;
+    f.running_var = net->dev_params + net->params[cv.p_var].info.offset;
+    f.scale = net->dev_params + cv.scale_off;
+    f.shift = net->dev_params + cv.shift_off;
+    f.save_mean = c.save((int)ci);
+    f.save_invstd = c.save((int)ci) + ((C + 63) & ~63);
+    f.C = C;
+    f.eps = 1e-5f;
+    f.momentum = 0.9f;  // layers.py:68
+    HIP_TRY(vy_launch_bn_finalize(f, c.s));
+    BnApplyArgs ap;
+    memset(&ap, 0, sizeof ap);
+    ap.z = c.zplane((int)ci);
+    ap.scale = f.scale;
+    ap.shift = f.shift;
+    const PlaneT& op = net->planes[cv.out_plane];
+    ap.out = net->plane_ptr(cv.out_plane);
+    ap.B = B;
+    ap.H = zp.H;
+    ap.W = zp.W;
+    ap.C = C;
+    ap.o_Hp = zp.H * cv.ups + 2;
+    ap.o_Wp = zp.W * cv.ups + 2;
+    ap.o_cs = op.C;
+    ap.o_co = cv.out_co;
+    ap.ups = cv.ups;
+    if (cv.res_plane >= 0) {
+      ap.res = net->plane_ptr(cv.res_plane);
+      ap.r_cs = net->planes[cv.res_plane].C;
+      ap.r_co = cv.res_co;
+    }
+    HIP_TRY(vy_launch_bn_apply(ap, c.s));
+  }
+  return 0;
+}
+
+// dgrad launches of conv cv: gradient w.r.t. its input view, from dz stored in `dzp`
+BwdDgrad make_dgrad(const TrainCtx& c, const ConvT& cv, const float* dzp, int dz_cs, int dz_H, int dz_W,
+                    const float* addend, int add_cs, int add_co) {
+  vy_net* net = c.net;
+  BwdDgrad out;
+  const PlaneT& ip = net->planes[cv.in_plane];
+  ConvArgs a;
+  memset(&a, 0, sizeof a);
+  a.in = dzp;
+  a.w = net->dev_params + net->params[cv.p_weight].info.offset;
+  a.out = c.gplane(cv.in_plane);
+  a.res = addend;
+  a.r_cs = add_cs;
+  a.r_co = add_co;
+  a.B = net->B;
+  a.a_Hp = dz_H + 2;
+  a.a_Wp = dz_W + 2;
+  a.a_cs = dz_cs;
+  a.a_co = 0;
+  a.a_s = 1;
+  a.a_oy = a.a_ox = 1;
+  a.Kc = (cv.cout + 31) & ~31;
+  a.w_taps = cv.k * cv.k;
+  a.w_cin = cv.cin;
+  a.w_cout = cv.cout;
+  a.N = cv.cin;
+  a.o_Hp = ip.H + 2;
+  a.o_Wp = ip.W + 2;
+  a.o_cs = ip.C;
+  a.o_co = cv.in_co;
+  a.ups = 1;
+  a.dgrad = 1;
+  if (cv.stride == 1) {
+    a.LH = ip.H;
+    a.LW = ip.W;
+    a.M = net->B * ip.H * ip.W;
+    a.o_s = 1;
+    a.o_oy = a.o_ox = 1;
+    a.ntaps = cv.k * cv.k;
+    for (int t = 0; t < a.ntaps; ++t) {
+      a.tap_dy[t] = (signed char)(cv.k == 3 ? 1 - t / 3 : 0);
+      a.tap_dx[t] = (signed char)(cv.k == 3 ? 1 - t % 3 : 0);
+      a.tap_w[t] = (unsigned char)t;
+    }
+    out.a[out.n++] = a;
+  } else {
+    // stride 2, 3x3, pad 1: input pixel (2y'+py, 2x'+px) receives taps with (py+1-kh), (px+1-kw) even
+    for (int py = 0; py < 2; ++py)
+      for (int px = 0; px < 2; ++px) {
+        ConvArgs q = a;
+        q.LH = ip.H / 2;
+        q.LW = ip.W / 2;
+        q.M = net->B * q.LH * q.LW;
+        q.o_s = 2;
+        q.o_oy = 1 + py;
+        q.o_ox = 1 + px;
+        q.ntaps = 0;
+        for (int kh = 0; kh < 3; ++kh) {
+          if ((py + 1 - kh) & 1) continue;
+          for (int kw = 0; kw < 3; ++kw) {
+            if ((px + 1 - kw) & 1) continue;
+            q.tap_dy[q.ntaps] = (signed char)((py + 1 - kh) / 2);
+            q.tap_dx[q.ntaps] = (signed char)((px + 1 - kw) / 2);
+            q.tap_w[q.ntaps] = (unsigned char)(kh * 3 + kw);
+            ++q.ntaps;
+          }
+        }
+        out.a[out.n++] = q;
+      }
+  }
+  return out;
+}
+
+int launch_wgrad(const TrainCtx& c, size_t ci, const float* dzp, int dz_cs, int Ho, int Wo) {
+  vy_net* net = c.net;
+  const ConvT& cv = net->convs[ci];
+  const PlaneT& ip = net->planes[cv.in_plane];
+  WgradArgs w;
+  memset(&w, 0, sizeof w);
+  w.dz = dzp;
+  w.a = net->plane_ptr(cv.in_plane);
+  w.slabs = c.slabs();
+  w.zero = c.zero();
+  w.B = net->B;
+  w.Ho = Ho;
+  w.Wo = Wo;
+  w.M = net->B * Ho * Wo;
+  w.z_cs = dz_cs;
+  w.Cout = cv.cout;
+  w.a_Hp = ip.H + 2;
+  w.a_Wp = ip.W + 2;
+  w.a_cs = ip.C;
+  w.a_co = cv.in_co;
+  w.stride = cv.stride;
+  w.k = cv.k;
+  w.Cin = cv.cin;
+  w.splits = c.t->splits[ci];
+  w.k_per_split = c.t->kps[ci];
+  HIP_TRY(vy_launch_wgrad(w, c.s));
+  HIP_TRY(vy_launch_slab_reduce(c.slabs(), w.splits, (long long)cv.cout * cv.k * cv.k * cv.cin,
+                                c.grad_of(cv.p_weight), c.s));
+  return 0;
+}
+
+int backward_train(const TrainCtx& c, const float* x) {
+  vy_net* net = c.net;
+  const int B = net->B;
+  // which channel ranges of each gradient plane already hold a contribution
+  std::vector<std::vector<std::pair<int, int>>> touched(net->planes.size());
+  auto covered = [&](int plane, int lo, int hi) -> int {  // 1 accumulate, 0 overwrite, -1 partial overlap
+    for (auto& r : touched[plane])
+      if (lo < r.second && r.first < hi) return (r.first <= lo && hi <= r.second) ? 1 : -1;
+    return 0;
+  };
+  // the prediction planes' gradients were written by the loss kernel
+  for (int i = 0; i < 3; ++i) touched[net->head_plane[i]].push_back({0, net->planes[net->head_plane[i]].C});
+  // pending skip-connection gradients: block input plane view -> gradient view of the block output
+  struct Skip {
+    int plane, co;     // input view of the block (where the addend must land)
+    int src_plane, src_co;
+  };
+  std::vector<Skip> skips;
+  // gradient buckets: heads | stages.2 | stages.1 | stages.0 (contiguous parameter ranges)
+  auto bucket_of = [&](const ConvT& cv) {
+    if (cv.name.rfind("stages.2", 0) == 0) return 1;
+    if (cv.name.rfind("stages.1", 0) == 0) return 2;
+    if (cv.name.rfind("stages.0", 0) == 0) return 3;
+    return 0;
+  };
+  auto emit_bucket = [&](int bk) -> int {
+    if (!c.t->gb_cb) return 0;
+    int64_t lo = INT64_MAX, hi = 0;
+    for (const ConvT& cv : net->convs) {
+      if (bucket_of(cv) != bk) continue;
+      const int ps[6] = {cv.p_weight, cv.p_gamma, cv.p_beta, cv.p_bias, -1, -1};
+      for (int p : ps) {
+        if (p < 0) continue;
+        const vy_param_info& pi = net->params[p].info;
+        if (pi.offset < lo) lo = pi.offset;
+        const int64_t e = pi.offset + ((pi.size + 63) & ~(int64_t)63);
+        if (e > hi) hi = e;
+      }
+    }
+    if (hi <= lo) return 0;
+    if (int rc = c.t->gb_cb(c.t->gb_user, lo, hi - lo)) return fail(VY_ERR_STATE, "gradient bucket callback failed (%d)", rc);
+    return 0;
+  };
+  int cur_bucket = 0;
+  for (int ci = (int)net->convs.size() - 1; ci >= 0; --ci) {
+    const ConvT& cv = net->convs[ci];
+    const int bk = bucket_of(cv);
+    if (bk != cur_bucket) {
+      if (int rc = emit_bucket(cur_bucket)) return rc;
+      cur_bucket = bk;
+    }
+    const float* dzp;
+    int dz_cs, dzH, dzW;
+    if (cv.p_gamma < 0) {
+      // prediction conv: dz = d(loss)/d(pred) as written by the loss kernel
+      const PlaneT& pp = net->planes[cv.out_plane];
+      dzp = c.gplane(cv.out_plane);
+      dz_cs = pp.C;
+      dzH = pp.H;
+      dzW = pp.W;
+      const int chunks = vy_colsum_chunks(B, pp.H, pp.W, 2048);
+      HIP_TRY(vy_launch_colsum(dzp, B, pp.H, pp.W, pp.C, 0, cv.cout, 2048, c.partials(), c.s));
+      HIP_TRY(vy_launch_reduce_partials(c.partials(), chunks, cv.cout, c.sums_local(), c.s));
+      HIP_TRY(vy_launch_f64_to_f32(c.sums_local(), c.grad_of(cv.p_bias), cv.cout, c.s));
+    } else {
+      const ZPlane& zp = c.t->z[ci];
+      const PlaneT& op = net->planes[cv.out_plane];
+      if (covered(cv.out_plane, cv.out_co, cv.out_co + cv.cout) != 1)
+        return fail(VY_ERR_STATE, "internal: gradient of '%s' output was never produced", cv.name.c_str());
+      BnBwdArgs bb;
+      memset(&bb, 0, sizeof bb);
+      bb.g = c.gplane(cv.out_plane);
+      bb.z = c.zplane(ci);
+      bb.scale = net->dev_params + cv.scale_off;
+      bb.shift = net->dev_params + cv.shift_off;
+      bb.save_mean = c.save(ci);
+      bb.save_invstd = c.save(ci) + ((cv.cout + 63) & ~63);
+      bb.coef = c.coef();
+      bb.partials = c.partials();
+      bb.B = B;
+      bb.H = zp.H;
+      bb.W = zp.W;
+      bb.C = cv.cout;
+      bb.g_Hp = zp.H * cv.ups + 2;
+      bb.g_Wp = zp.W * cv.ups + 2;
+      bb.g_cs = op.C;
+      bb.g_co = cv.out_co;
+      bb.ups = cv.ups;
+      bb.chunk = 2048;
+      HIP_TRY(vy_launch_bn_bwd_reduce(bb, c.s));
+      HIP_TRY(vy_launch_reduce_partials(c.partials(), vy_bn_bwd_chunks(bb), 2 * cv.cout, c.sums_local(), c.s));
+      double count = (double)B * zp.H * zp.W;
+      if (int rc = combine_sums(c, cv, 2 * cv.cout, &count)) return rc;
+      BnBwdFinalizeArgs f;
+      memset(&f, 0, sizeof f);
+      f.sums = c.sums_global();
+      f.local_sums = c.sums_local();
+      f.count = count;
+      f.gamma = net->dev_params + net->params[cv.p_gamma].info.offset;
+      f.save_invstd = bb.save_invstd;
+      f.dgamma = c.grad_of(cv.p_gamma);
+      f.dbeta = c.grad_of(cv.p_beta);
+      f.coef = c.coef();
+      f.C = cv.cout;
+      HIP_TRY(vy_launch_bn_bwd_finalize(f, c.s));
+      HIP_TRY(vy_launch_bn_bwd_apply(bb, c.s));
+      dzp = c.zplane(ci);
+      dz_cs = zp.C;
+      dzH = zp.H;
+      dzW = zp.W;
+      if (cv.res_plane >= 0) skips.push_back({cv.res_plane, cv.res_co, cv.out_plane, cv.out_co});
+    }
+    // weight gradient
+    if (cv.is_stem) {
+      StemWgradArgs sw;
+      sw.x = x;
+      sw.dz = dzp;
+      sw.partials = c.partials();
+      sw.B = B;
+      sw.H = net->H;
+      sw.W = net->W;
+      HIP_TRY(vy_launch_stem_wgrad(sw, c.s));
+      HIP_TRY(vy_launch_reduce_partials(c.partials(), vy_stem_wgrad_blocks(B, net->H, net->W), 864,
+                                        c.sums_local(), c.s));
+      HIP_TRY(vy_launch_f64_to_f32(c.sums_local(), c.grad_of(cv.p_weight), 864, c.s));
+      continue;  // no gradient w.r.t. the image
+    }
+    if (int rc = launch_wgrad(c, (size_t)ci, dzp, dz_cs, dzH, dzW)) return rc;
+    // data gradient into the input view
+    const int lo = cv.in_co, hi = cv.in_co + cv.cin;
+    const int cov = covered(cv.in_plane, lo, hi);
+    if (cov < 0) return fail(VY_ERR_STATE, "internal: partial gradient overlap at '%s'", cv.name.c_str());
+    const float* addend = nullptr;
+    int add_cs = 0, add_co = 0;
+    int skip_i = -1;
+    for (size_t k = 0; k < skips.size(); ++k)
+      if (skips[k].plane == cv.in_plane && skips[k].co == cv.in_co) skip_i = (int)k;
+    if (skip_i >= 0) {
+      if (cov == 1) return fail(VY_ERR_STATE, "internal: skip + accumulate at '%s'", cv.name.c_str());
+      addend = c.gplane(skips[skip_i].src_plane);
+      add_cs = net->planes[skips[skip_i].src_plane].C;
+      add_co = skips[skip_i].src_co;
+      skips.erase(skips.begin() + skip_i);
+    } else if (cov == 1) {
+      addend = c.gplane(cv.in_plane);
+      add_cs = net->planes[cv.in_plane].C;
+      add_co = cv.in_co;
+    }
+    const BwdDgrad dg = make_dgrad(c, cv, dzp, dz_cs, dzH, dzW, addend, add_cs, add_co);
+    for (int k = 0; k < dg.n; ++k) HIP_TRY(vy_launch_conv_igemm(dg.a[k], c.s));
+    if (cov == 0) touched[cv.in_plane].push_back({lo, hi});
+  }
+  if (int rc = emit_bucket(cur_bucket)) return rc;
+  if (!skips.empty()) return fail(VY_ERR_STATE, "internal: unresolved skip gradient");
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t vy_net_train_workspace_bytes(const vy_net* net, int32_t batch, int32_t height, int32_t width) {
+  if (!net) return 0;
+  if (vy_net_workspace_bytes(net, batch, height, width) == 0) return 0;
+  return train_plan(const_cast<vy_net*>(net), batch, height, width, false);
+}
+
+int vy_net_bind_train(vy_net* net, void* dev_ws, size_t bytes, int32_t batch, int32_t height, int32_t width,
+                      void* dev_grads, void* dev_momentum, void* stream) {
+  if (!net || !dev_ws || !dev_grads || !dev_momentum) return fail(VY_ERR_INVALID, "null argument");
+  if (vy_net_workspace_bytes(net, batch, height, width) == 0) return VY_ERR_INVALID;
+  const size_t need = train_plan(net, batch, height, width, false);
+  if (bytes < need) return fail(VY_ERR_INVALID, "training workspace too small: %zu < %zu bytes", bytes, need);
+  train_plan(net, batch, height, width, true);
+  VyTrain* t = net->train;
+  net->dev_ws = static_cast<unsigned char*>(dev_ws);
+  net->ws_bytes = bytes;
+  net->fold_uploaded = false;
+  t->grads = static_cast<float*>(dev_grads);
+  t->mom = static_cast<float*>(dev_momentum);
+  t->forward_done = false;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  HIP_TRY(hipMemsetAsync(dev_ws, 0, need, s));
+  return 0;
+}
+
+int vy_net_set_train_options(vy_net* net, float ignore_iou_thresh, int32_t label_smooth) {
+  if (!net) return fail(VY_ERR_INVALID, "net is null");
+  VyTrain* t = get_train(net);
+  t->ignore_iou = ignore_iou_thresh;
+  t->label_smooth = label_smooth ? 1 : 0;
+  return 0;
+}
+
+int vy_net_train_forward(vy_net* net, const float* x, const float* gt_boxes, int32_t M, const float* obj_t,
+                         const float* centers_t, const float* scales_t, const float* weights_t,
+                         const float* clas_t, float* losses, void* stream) {
+  if (!net || !x || !obj_t || !centers_t || !scales_t || !weights_t || !clas_t || !losses || (M > 0 && !gt_boxes))
+    return fail(VY_ERR_INVALID, "null argument");
+  if (int rc = net->check_ready()) return rc;
+  VyTrain* t = net->train;
+  if (!t || !t->grads || t->B != net->B || t->H != net->H || t->W != net->W)
+    return fail(VY_ERR_STATE, "training workspace not bound (vy_net_bind_train)");
+  TrainCtx c{net, t, static_cast<hipStream_t>(stream)};
+  if (int rc = forward_train(c, x)) return rc;
+  const DetArgs d = net->det_args();
+  LossArgs la;
+  memset(&la, 0, sizeof la);
+  int N = 0;
+  for (int i = 0; i < 3; ++i) {
+    la.head[i] = d.head[i];
+    la.dpred[i] = c.gplane(net->head_plane[i]);
+    N += 3 * d.head[i].H * d.head[i].W;
+  }
+  la.gt_boxes = gt_boxes;
+  la.obj_t = obj_t;
+  la.centers_t = centers_t;
+  la.scales_t = scales_t;
+  la.weights_t = weights_t;
+  la.clas_t = clas_t;
+  la.partials = reinterpret_cast<float*>(net->dev_ws + t->loss_part_off);
+  la.B = net->B;
+  la.C = net->num_class;
+  la.M = M;
+  la.N = N;
+  la.ignore_iou_thresh = t->ignore_iou;
+  la.label_smooth = t->label_smooth;
+  HIP_TRY(vy_launch_loss(la, c.s));
+  HIP_TRY(vy_launch_loss_reduce(la.partials, vy_loss_blocks_per_image(N), net->B, losses, c.s));
+  t->forward_done = true;
+  t->M = M;
+  return 0;
+}
+
+int vy_net_train_backward(vy_net* net, const float* x, void* stream) {
+  if (!net || !x) return fail(VY_ERR_INVALID, "null argument");
+  if (int rc = net->check_ready()) return rc;
+  VyTrain* t = net->train;
+  if (!t || !t->forward_done) return fail(VY_ERR_STATE, "vy_net_train_backward without a recorded forward");
+  TrainCtx c{net, t, static_cast<hipStream_t>(stream)};
+  t->forward_done = false;
+  return backward_train(c, x);
+}
+
+int vy_net_param_set_opt(vy_net* net, int32_t i, float lr_mult, float wd_mult, int32_t enabled) {
+  if (!net || i < 0 || i >= (int32_t)net->params.size()) return fail(VY_ERR_INVALID, "bad argument");
+  VyTrain* t = get_train(net);
+  t->lr_mult[i] = lr_mult;
+  t->wd_mult[i] = wd_mult;
+  t->enabled[i] = enabled ? 1 : 0;
+  // refresh the segment table in place if it is already planned
+  int si = 0;
+  for (int p = 0; p < (int)net->params.size(); ++p) {
+    if (!net->params[p].info.trainable) continue;
+    if (p == i && si < (int)t->segs.size()) {
+      t->segs[si].lr_mult = lr_mult;
+      t->segs[si].wd_mult = wd_mult;
+      t->segs[si].enabled = enabled ? 1 : 0;
+      t->seg_uploaded = false;
+    }
+    ++si;
+  }
+  return 0;
+}
+
+int vy_net_sgd_step(vy_net* net, float lr, float momentum, float wd, float rescale_grad, void* stream) {
+  if (!net) return fail(VY_ERR_INVALID, "net is null");
+  if (int rc = net->check_ready()) return rc;
+  VyTrain* t = net->train;
+  if (!t || !t->grads) return fail(VY_ERR_STATE, "training workspace not bound (vy_net_bind_train)");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  SgdSeg* segs = reinterpret_cast<SgdSeg*>(net->dev_ws + t->seg_off);
+  int32_t* chunks = reinterpret_cast<int32_t*>(net->dev_ws + t->chunk_off);
+  if (!t->seg_uploaded) {
+    HIP_TRY(hipMemcpyAsync(segs, t->segs.data(), t->segs.size() * sizeof(SgdSeg), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(chunks, t->chunk_seg.data(), t->chunk_seg.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipStreamSynchronize(s));  // pageable host vectors; only when the table changed
+    t->seg_uploaded = true;
+  }
+  HIP_TRY(vy_launch_sgd(net->dev_params, t->grads, t->mom, segs, chunks, (int)(t->chunk_seg.size() / 2), lr, momentum,
+                        wd, rescale_grad, s));
+  return 0;
+}
+
+int vy_net_grad_get(vy_net* net, int32_t i, float* host_dst, void* stream) {
+  if (!net || !host_dst || i < 0 || i >= (int32_t)net->params.size()) return fail(VY_ERR_INVALID, "bad argument");
+  VyTrain* t = net->train;
+  if (!t || !t->grads) return fail(VY_ERR_STATE, "training workspace not bound");
+  const vy_param_info& pi = net->params[i].info;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  std::vector<float> tmp((size_t)pi.size);
+  HIP_TRY(hipMemcpyAsync(tmp.data(), t->grads + pi.offset, sizeof(float) * pi.size, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  if (pi.ndim == 4) {
+    const int O = pi.shape[0], I = pi.shape[1], kk = pi.shape[2] * pi.shape[3];
+    for (int o = 0; o < O; ++o)
+      for (int ii = 0; ii < I; ++ii)
+        for (int tt = 0; tt < kk; ++tt) host_dst[((size_t)o * I + ii) * kk + tt] = tmp[((size_t)o * kk + tt) * I + ii];
+  } else {
+    memcpy(host_dst, tmp.data(), sizeof(float) * pi.size);
+  }
+  return 0;
+}
+
+int vy_net_set_sync_bn(vy_net* net, int32_t world, vy_allreduce_cb cb, void* user) {
+  if (!net || world < 1) return fail(VY_ERR_INVALID, "bad argument");
+  if (world > 1 && !cb) return fail(VY_ERR_INVALID, "world > 1 needs an all-reduce callback");
+  VyTrain* t = get_train(net);
+  t->world = world;
+  t->ar_cb = cb;
+  t->ar_user = user;
+  return 0;
+}
+
+int vy_net_set_grad_bucket_cb(vy_net* net, vy_grad_bucket_cb cb, void* user) {
+  if (!net) return fail(VY_ERR_INVALID, "net is null");
+  VyTrain* t = get_train(net);
+  t->gb_cb = cb;
+  t->gb_user = user;
+  return 0;
+}
+
+}  // extern "C"

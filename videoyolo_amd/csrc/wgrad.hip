@@ -1,0 +1,142 @@
+// wgrad.hip — weight gradient of the 3x3 / 1x1 convolutions on the fp32 matrix core.
+//
+// What mxnet's autograd computes for Convolution's weight under train_yolov3.py:631:
+//   dW[o][tap][cin] = sum over output pixels p of  dz[p][o] * a[p*stride + tap][cin]
+// GEMM view: D[o][n] = sum_p A[o][p] * B[p][n],  n = tap*Cin + cin; the reduction runs over the
+// B*Ho*Wo pixels (10^4..10^6) while the output is small, so the pixel range is split over blocks
+// (split-K); each split writes its own fp32 slab and vy_launch_slab_reduce adds the slabs in index
+// order (deterministic, no atomics).
+//
+// Both operands are "k-major" in HBM already: a pixel's channel vector is contiguous, so the LDS
+// tiles are [32 pixels][128 channels] exactly as loaded (LDS-DMA, 16 B per lane, rows of 512 B) and
+// the MFMA fragments A[i=o][k=p], B[k=p][j=n] are ds_read_b32 of 32 consecutive floats per
+// half-wave (conflict-free, no swizzle).  Block tile 128(o) x 128(n) x 32(p), 4 waves 2x2,
+// 64 accumulator VGPRs per lane, 64 KiB LDS double buffer -> 2 blocks / CU.
+#include "kernels.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+
+__global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a, const int tiles_n) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int BM = 128, BN = 128, TILE = 32 * 128 * 4, STAGE = 2 * TILE;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int h = lane >> 5, lrow = lane & 31;
+  const int tile_m = blockIdx.x / tiles_n, tile_n = blockIdx.x - tile_m * tiles_n;
+  const int o0 = tile_m * BM, n0 = tile_n * BN;
+  const int Ntot = a.k * a.k * a.Cin;
+  const int split = blockIdx.y;
+  const int p_begin = split * a.k_per_split;
+  int p_end = p_begin + a.k_per_split;
+  if (p_end > a.M) p_end = a.M;
+  const int T = (p_end - p_begin + 31) / 32;
+
+  // this lane's fixed column chunk in both tiles
+  const int chunk = lane & 31;            // 16-B chunk inside a 512-B row
+  const int ao = o0 + chunk * 4;          // dz channel of this chunk
+  const bool a_ok = ao < a.z_cs;          // (padded) channel exists in the dz plane
+  const int bn = n0 + chunk * 4;          // n column of this chunk
+  const bool b_ok = bn < Ntot;
+  const int tap = b_ok ? bn / a.Cin : 0;
+  const int cin = b_ok ? bn - tap * a.Cin : 0;
+  const int pad = a.k >> 1;
+  const int dy = a.k == 3 ? tap / 3 - pad : 0, dx = a.k == 3 ? tap % 3 - pad : 0;
+  const int Hzp = a.Ho + 2, Wzp = a.Wo + 2;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+  auto stage = [&](int t, int buf) {
+    unsigned char* sA = smem + buf * STAGE;
+    unsigned char* sB = sA + TILE;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int q = j * 4 + wave;
+      const int p = p_begin + t * 32 + 2 * q + h;
+      const float* pa = a.zero;
+      const float* pb = a.zero;
+      if (p < p_end) {
+        const int ox = p % a.Wo;
+        const int tt = p / a.Wo;
+        const int oy = tt % a.Ho;
+        const int b = tt / a.Ho;
+        if (a_ok) pa = a.dz + ((long long)(b * Hzp + oy + 1) * Wzp + ox + 1) * a.z_cs + ao;
+        if (b_ok)
+          pb = a.a + ((long long)(b * a.a_Hp + oy * a.stride + 1 + dy) * a.a_Wp + ox * a.stride + 1 + dx) * a.a_cs +
+               a.a_co + cin;
+      }
+      __builtin_amdgcn_global_load_lds(pa, LDS_PTR(sA + q * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(pb, LDS_PTR(sB + q * 1024), 16, 0, 0);
+    }
+  };
+
+  if (T > 0) stage(0, 0);
+  for (int t = 0; t < T; ++t) {
+    __syncthreads();
+    if (t + 1 < T) stage(t + 1, (t + 1) & 1);
+    const float* tA = reinterpret_cast<const float*>(smem + (t & 1) * STAGE);
+    const float* tB = tA + 32 * 128;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      const int krow = (2 * s + h) * 128;
+      float av[2], bv[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) av[i] = tA[krow + (wm * 2 + i) * 32 + lrow];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) bv[j] = tB[krow + (wn * 2 + j) * 32 + lrow];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+    }
+  }
+
+  float* slab = a.slabs + (long long)split * a.Cout * Ntot;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int n = n0 + (wn * 2 + j) * 32 + lrow;
+    if (n >= Ntot) continue;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int o = o0 + (wm * 2 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (o < a.Cout) slab[(long long)o * Ntot + n] = acc[i][j][r];
+      }
+  }
+#endif
+}
+
+hipError_t vy_launch_wgrad(const WgradArgs& a, hipStream_t s) {
+  if (a.Cin % 32 != 0 || a.k_per_split % 32 != 0 || a.splits < 1 || (a.z_cs & 3) || (a.a_cs & 3) || (a.a_co & 3))
+    return hipErrorInvalidValue;
+  const int Ntot = a.k * a.k * a.Cin;
+  const int tiles_m = (a.Cout + 127) / 128, tiles_n = (Ntot + 127) / 128;
+  hipLaunchKernelGGL(wgrad_kernel, dim3(tiles_m * tiles_n, a.splits), dim3(256), 0, s, a, tiles_n);
+  return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slabs, int splits, long long n,
+                                                          float* __restrict__ dst) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float s = 0.0f;
+  for (int k = 0; k < splits; ++k) s += slabs[(long long)k * n + i];
+  dst[i] = s;
+}
+
+hipError_t vy_launch_slab_reduce(const float* slabs, int splits, long long n, float* dst, hipStream_t s) {
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, slabs, splits, n, dst);
+  return hipGetLastError();
+}

@@ -127,7 +127,11 @@ class YOLOV3(object):
         self._host = {}          # name -> numpy (reference layout) while not on a device
         self._dev_params = None  # torch uint8 tensor holding the device parameter buffer
         self._ws = None          # torch uint8 workspace
-        self._plan = None        # (B, H, W) the workspace is planned for
+        self._plan = None        # (B, H, W, train?) the workspace is planned for
+        self._grads = None       # torch float32 flat gradient buffer (device layout, training only)
+        self._mom = None         # torch float32 flat SGD momentum buffer
+        self._train_x = None     # image batch of the recorded forward (stem weight gradient)
+        self._cb_keep = []       # ctypes callbacks kept alive
         self._device = None
         self._hybrid = False
         _lib.check(self._lib.vy_net_set_nms(self._h, nms_thresh, nms_topk, post_nms))
@@ -354,21 +358,31 @@ class YOLOV3(object):
         return twin
 
     # ------------------------------------------------------------------ execution
-    def _ensure_plan(self, b, h, w):
+    def _ensure_plan(self, b, h, w, train=False):
         torch = _torch()
         if self._dev_params is None:
             raise RuntimeError("parameters are not on a device: call net.collect_params().reset_ctx(ctx)")
-        if self._plan == (b, h, w):
+        if self._plan is not None and self._plan[:3] == (b, h, w) and (self._plan[3] or not train):
             return
-        need = self._lib.vy_net_workspace_bytes(self._h, b, h, w)
+        fn = self._lib.vy_net_train_workspace_bytes if train else self._lib.vy_net_workspace_bytes
+        need = fn(self._h, b, h, w)
         if need == 0:
             raise _lib.VyError(-1, self._lib.vy_last_error().decode())
         if self._ws is None or self._ws.numel() < need:
             self._ws = None
             self._ws = torch.empty(need, dtype=torch.uint8, device=self._device)
-        _lib.check(self._lib.vy_net_bind_workspace(self._h, ctypes.c_void_p(self._ws.data_ptr()),
-                                                   self._ws.numel(), b, h, w, self._stream()))
-        self._plan = (b, h, w)
+        if train:
+            if self._grads is None:
+                n = self._lib.vy_net_param_bytes(self._h) // 4
+                self._grads = torch.zeros(n, dtype=torch.float32, device=self._device)
+                self._mom = torch.zeros(n, dtype=torch.float32, device=self._device)
+            _lib.check(self._lib.vy_net_bind_train(
+                self._h, ctypes.c_void_p(self._ws.data_ptr()), self._ws.numel(), b, h, w,
+                ctypes.c_void_p(self._grads.data_ptr()), ctypes.c_void_p(self._mom.data_ptr()), self._stream()))
+        else:
+            _lib.check(self._lib.vy_net_bind_workspace(self._h, ctypes.c_void_p(self._ws.data_ptr()),
+                                                       self._ws.numel(), b, h, w, self._stream()))
+        self._plan = (b, h, w, bool(train))
 
     def _as_input(self, x):
         torch = _torch()
@@ -382,11 +396,95 @@ class YOLOV3(object):
         return x
 
     def __call__(self, x, *args, return_index=False):
+        """Mode is selected by the autograd state, like YOLOV3T.hybrid_forward (yolo3.py:1179-1206)."""
         if autograd.is_training():
-            raise NotImplementedError(
-                "training-mode forward (yolo3.py:1179-1192) is not built yet in this round; "
-                "inference: call outside autograd.record()/train_mode()")
+            if autograd.is_recording():
+                if len(args) != 6:
+                    raise ValueError("training call: net(x, gt_boxes, obj_t, centers_t, scales_t, weights_t, clas_t)")
+                return self.forward_train(x, *args)
+            return self.forward_train_mode(x)
         return self.detect(x, return_index=return_index)
+
+    def _dev(self, a):
+        torch = _torch()
+        if not isinstance(a, torch.Tensor):
+            a = torch.as_tensor(np.asarray(a, np.float32))
+        return a.to(device=self._device, dtype=torch.float32).contiguous()
+
+    def forward_train(self, x, gt_boxes, obj_t, centers_t, scales_t, weights_t, clas_t):
+        """Recording branch (yolo3.py:1181-1187): the four (B,) losses.  The network gradient is
+        produced by ``autograd.backward(...)`` / ``net.backward()`` afterwards."""
+        torch = _torch()
+        x = self._as_input(x)
+        b, _, h, w = x.shape
+        tg = [self._dev(t) for t in (gt_boxes, obj_t, centers_t, scales_t, weights_t, clas_t)]
+        m = int(tg[0].shape[1])
+        with torch.cuda.device(self._device):
+            self._ensure_plan(b, h, w, train=True)
+            n = self._lib.vy_net_num_anchors(self._h)
+            c = len(self._classes)
+            want = [(b, m, 4), (b, n, 1), (b, n, 2), (b, n, 2), (b, n, 2), (b, n, c)]
+            for t, shp in zip(tg, want):
+                if tuple(t.shape) != shp:
+                    raise ValueError("target shape %s, expected %s" % (tuple(t.shape), shp))
+            _lib.check(self._lib.vy_net_set_train_options(
+                self._h, self._ignore_iou_thresh, int(bool(self._target_generator._label_smooth))))
+            losses = torch.empty((4, b), dtype=torch.float32, device=self._device)
+            p = [ctypes.c_void_p(t.data_ptr()) for t in tg]
+            _lib.check(self._lib.vy_net_train_forward(
+                self._h, ctypes.c_void_p(x.data_ptr()), p[0], m, p[1], p[2], p[3], p[4], p[5],
+                ctypes.c_void_p(losses.data_ptr()), self._stream()))
+        self._train_x = x
+        autograd._register(self)
+        return losses[0], losses[1], losses[2], losses[3]
+
+    def backward(self):
+        """autograd.backward(sum of the four losses) for this net (train_yolov3.py:631)."""
+        torch = _torch()
+        if self._train_x is None:
+            raise RuntimeError("backward() without a recorded forward")
+        with torch.cuda.device(self._device):
+            _lib.check(self._lib.vy_net_train_backward(self._h, ctypes.c_void_p(self._train_x.data_ptr()),
+                                                       self._stream()))
+        self._train_x = None
+
+    def forward_train_mode(self, x):
+        """``autograd.train_mode()`` without recording (transforms.py:190-193): the 8-tuple of
+        yolo3.py:1189-1192.  Its consumers read items 1-3 (anchors, offsets, fake feature maps),
+        which are constants of the input shape; the prediction-dependent items are not provided by
+        this path (None)."""
+        torch = _torch()
+        x = x if hasattr(x, "shape") else np.asarray(x)
+        b, _, h, w = x.shape
+        anchors, offsets, fms = [], [], []
+        table = [[116, 90, 156, 198, 373, 326], [30, 61, 62, 45, 59, 119], [10, 13, 16, 30, 33, 23]]
+        for i, s in enumerate((32, 16, 8)):
+            hh, ww = h // s, w // s
+            anchors.append(np.array(table[i], np.float32).reshape(1, 1, 3, 2))
+            gx, gy = np.meshgrid(np.arange(ww), np.arange(hh))
+            offsets.append(np.stack([gx, gy], -1).astype(np.float32).reshape(1, hh * ww, 1, 2))
+            fms.append(np.zeros((1, 1, hh, ww), np.float32))
+        return (None, anchors, offsets, fms, None, None, None, None)
+
+    def grad(self, name):
+        """Gradient of parameter `name` in the reference layout (numpy)."""
+        torch = _torch()
+        p = self._params[name]
+        out = np.empty(p.shape, np.float32)
+        with torch.cuda.device(self._device):
+            _lib.check(self._lib.vy_net_grad_get(self._h, p.index, out.ctypes.data_as(ctypes.c_void_p),
+                                                 self._stream()))
+        return out
+
+    def _sync_opts(self):
+        for p in self._params.values():
+            _lib.check(self._lib.vy_net_param_set_opt(self._h, p.index, float(p.lr_mult), float(p.wd_mult),
+                                                      int(p.trainable and p.grad_req != 'null')))
+
+    def sgd_step(self, lr, momentum, wd, rescale_grad):
+        torch = _torch()
+        with torch.cuda.device(self._device):
+            _lib.check(self._lib.vy_net_sgd_step(self._h, lr, momentum, wd, rescale_grad, self._stream()))
 
     def detect(self, x, return_index=False):
         """Inference branch of YOLOV3T.hybrid_forward (yolo3.py:1194-1206): returns
@@ -412,7 +510,7 @@ class YOLOV3(object):
     def read_head(self, i):
         """Prediction-conv output of head i (stride 32,16,8) of the last forward, NCHW."""
         torch = _torch()
-        b, h, w = self._plan
+        b, h, w = self._plan[:3]
         div = (32, 16, 8)[i]
         out = torch.empty((b, 3 * (5 + len(self._classes)), h // div, w // div), dtype=torch.float32,
                           device=self._device)

@@ -1,0 +1,155 @@
+"""Multi-GPU plumbing: one process per GPU, ``torch.distributed`` over RCCL (backend "nccl" on
+ROCm) / xGMI; ``gloo`` on CPU for the tests.  What shards:
+
+  inference   frames are independent: ``scatter_frames`` gives each rank its slice
+              (gluon.utils.split_and_load(..., even_split=False), detect_yolo3.py:211-213); no collective.
+  training    data parallel: one sum all-reduce of the flat gradient buffer per step (246.5 MB fp32),
+              bucketed and overlapped with the backward pass (heads, stage 2, 1, 0);
+              SyncBatchNorm layers all-reduce their [2][C] statistics forward and backward.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+
+def _dist():
+    import torch.distributed as dist
+    return dist
+
+
+def is_initialized():
+    dist = _dist()
+    return dist.is_available() and dist.is_initialized()
+
+
+def world_size():
+    return _dist().get_world_size() if is_initialized() else 1
+
+
+def rank():
+    return _dist().get_rank() if is_initialized() else 0
+
+
+def init_process_group(backend=None):
+    """Initialise from the torchrun environment (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_*)."""
+    import torch
+    dist = _dist()
+    if dist.is_initialized():
+        return
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29500")
+    r, w = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    if backend is None:
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    kw = {}
+    if backend == "nccl":
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        torch.cuda.set_device(local)
+        kw["device_id"] = torch.device("cuda", local)
+    dist.init_process_group(backend, rank=r, world_size=w, **kw)
+
+
+def split_sizes(n, parts):
+    """even_split=False slice sizes: the first n % parts slices get one extra element."""
+    base, extra = divmod(n, parts)
+    return [base + (1 if i < extra else 0) for i in range(parts)]
+
+
+def scatter_frames(batch, r=None, w=None):
+    """This rank's slice of a frame batch along axis 0 (numpy or torch)."""
+    r = rank() if r is None else r
+    w = world_size() if w is None else w
+    sizes = split_sizes(len(batch), w)
+    lo = sum(sizes[:r])
+    return batch[lo:lo + sizes[r]]
+
+
+def allreduce_(tensor):
+    """In-place sum over all ranks (no-op without a process group)."""
+    if is_initialized() and world_size() > 1:
+        _dist().all_reduce(tensor)
+    return tensor
+
+
+def gather_detections(ids, scores, bboxes):
+    """Host gather of per-rank (B_r,100,·) results to rank 0 (detect_yolo3.py:233 as_numpy concat)."""
+    import torch
+    if not is_initialized() or world_size() == 1:
+        return ids, scores, bboxes
+    dist = _dist()
+    packed = torch.cat([ids, scores, bboxes], dim=-1).contiguous()
+    sizes = [None] * world_size()
+    dist.all_gather_object(sizes, int(packed.shape[0]))
+    outs = [torch.empty((s,) + tuple(packed.shape[1:]), dtype=packed.dtype, device=packed.device) for s in sizes]
+    dist.all_gather(outs, packed) if len(set(sizes)) == 1 else [
+        dist.broadcast(outs[i] if i != rank() else packed, src=i) for i in range(world_size())]
+    if len(set(sizes)) != 1:
+        outs[rank()] = packed
+    full = torch.cat(outs, 0)
+    return full[..., 0:1], full[..., 1:2], full[..., 2:]
+
+
+class SyncBatchNormHook(object):
+    """Installs the statistics all-reduce for SyncBatchNorm(num_devices) (train_yolov3.py:352-354):
+    the library calls back with a device pointer into the net's workspace and a count of doubles."""
+
+    def __init__(self, net):
+        import torch
+        from . import _lib
+        self.net = net
+
+        def cb(user, ptr, count):
+            try:
+                ws = net._ws
+                off = int(ptr) - ws.data_ptr()
+                view = ws[off:off + 8 * count].view(torch.float64)
+                _dist().all_reduce(view)
+                return 0
+            except Exception:  # pragma: no cover - surfaced as a library error
+                import traceback
+                traceback.print_exc()
+                return 1
+        self._cb = _lib.ALLREDUCE_CB(cb)
+        net._cb_keep.append(self._cb)
+        _lib.check(net._lib.vy_net_set_sync_bn(net._h, world_size(), self._cb, None))
+
+
+class GradBucketOverlap(object):
+    """Bucketed gradient all-reduce overlapped with backward: the library reports each finished
+    contiguous gradient range; it is all-reduced on a side stream after an event on the compute
+    stream, while the remaining backward kernels keep the compute stream busy."""
+
+    def __init__(self, net):
+        import torch
+        from . import _lib
+        self.net = net
+        self.stream = torch.cuda.Stream(device=net._device) if net._device is not None else None
+        self.pending = []
+
+        def cb(user, off, count):
+            try:
+                if not is_initialized() or world_size() == 1:
+                    return 0
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream(net._device))
+                with torch.cuda.stream(self.stream):
+                    self.stream.wait_event(ev)
+                    work = _dist().all_reduce(net._grads[off:off + count], async_op=True)
+                self.pending.append(work)
+                return 0
+            except Exception:  # pragma: no cover
+                import traceback
+                traceback.print_exc()
+                return 1
+        self._cb = _lib.GRAD_BUCKET_CB(cb)
+        net._cb_keep.append(self._cb)
+        _lib.check(net._lib.vy_net_set_grad_bucket_cb(net._h, self._cb, None))
+
+    def finish(self):
+        import torch
+        for w in self.pending:
+            w.wait()
+        self.pending = []
+        if self.stream is not None:
+            torch.cuda.current_stream(self.net._device).wait_stream(self.stream)
