@@ -183,6 +183,10 @@ int vy_net_sgd_step(vy_net* net, float lr, float momentum, float wd, float resca
 /* Gradient of parameter i in the REFERENCE layout to host memory (tests / checkpoints). */
 int vy_net_grad_get(vy_net* net, int32_t i, float* host_dst, void* stream);
 
+/* Parity tap: gradient w.r.t. the output of cell `name` after vy_net_train_backward, as NCHW at the
+ * resolution the output is stored (x2 for the transition cells). */
+int vy_net_read_grad_activation(vy_net* net, const char* name, float* dst_dev, void* stream);
+
 /* SyncBatchNorm(num_devices) (train_yolov3.py:352-354).  With world > 1 the BatchNorm layers that
  * the reference builds with the passed norm_layer — the stem and the five stride-2 convs of
  * Darknet-53 (three_darknet.py:163-181; the residual blocks hard-code BatchNorm, :193-194, and

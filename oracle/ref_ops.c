@@ -100,9 +100,9 @@ void vyo_bn_fold(const float* gamma, const float* beta, const float* mean, const
 }
 
 /* Train-mode BatchNorm forward over (N,H,W) per channel + LeakyReLU.  [UPSTREAM-RECALLED]
- * mxnet BatchNorm(fix_gamma=False, use_global_stats=False): mean = sum/x count, var = biased
- * variance, y = (x-mean)/sqrt(var+eps)*gamma+beta.  Sums are accumulated in double so that the
- * checker is an accuracy reference (the device reduces in fp32 trees; compare with tolerance).
+ * mxnet BatchNorm(fix_gamma=False, use_global_stats=False): mean = sum/count, var = biased
+ * variance, y = (x-mean)/sqrt(var+eps)*gamma+beta.  Sums are accumulated in double and rounded to
+ * fp32 mean / var (the device does the same, so both sides normalise with identical constants).
  * Outputs the batch mean/var (biased) so the caller can update running stats. */
 void vyo_bn_train(const float* x, int N, int C, int HW, const float* gamma, const float* beta,
                   float eps, int leaky, float* y, float* mean_out, float* var_out) {
@@ -123,12 +123,16 @@ void vyo_bn_train(const float* x, int N, int C, int HW, const float* gamma, cons
     const float mf = (float)m, vf = (float)v;
     mean_out[c] = mf;
     var_out[c] = vf;
+    /* applied as ONE fma with scale = gamma*invstd, shift = beta - mean*scale (the device's form;
+     * differs from the textbook (x-mean)*invstd*gamma+beta by rounding only) */
     const float inv = 1.0f / sqrtf(vf + eps);
+    const float sc = gamma[c] * inv;
+    const float sh = fmaf(-mf, sc, beta[c]);
     for (int n = 0; n < N; ++n) {
       const float* xr = x + ((size_t)n * C + c) * HW;
       float* yr = y + ((size_t)n * C + c) * HW;
       for (int i = 0; i < HW; ++i) {
-        float t = (xr[i] - mf) * inv * gamma[c] + beta[c];
+        float t = fmaf(xr[i], sc, sh);
         yr[i] = leaky ? vy_leaky(t) : t;
       }
     }

@@ -66,6 +66,7 @@ SIGNATURES.update({
     "vy_net_param_set_opt": (ctypes.c_int, [_vp, _i32, _f32, _f32, _i32]),
     "vy_net_sgd_step": (ctypes.c_int, [_vp, _f32, _f32, _f32, _f32, _vp]),
     "vy_net_grad_get": (ctypes.c_int, [_vp, _i32, _vp, _vp]),
+    "vy_net_read_grad_activation": (ctypes.c_int, [_vp, ctypes.c_char_p, _vp, _vp]),
     "vy_net_set_sync_bn": (ctypes.c_int, [_vp, _i32, ALLREDUCE_CB, _vp]),
     "vy_net_set_grad_bucket_cb": (ctypes.c_int, [_vp, GRAD_BUCKET_CB, _vp]),
 })

@@ -230,25 +230,27 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a, const
   // train-mode BatchNorm: per-tile column sums of the raw accumulators (deterministic: fixed
   // order inside the tile, tiles are combined in order by the finalize kernel)
   if (a.stats) {
-    float s1[TN], s2[TN];
+    // double accumulation: var = E[x^2] - mean^2 cancels badly in fp32 when |mean| >> std, and the
+    // batch statistics must round to the same fp32 mean / var as the CPU checker's
+    double s1[TN], s2[TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-      s1[j] = 0.0f;
-      s2[j] = 0.0f;
+      s1[j] = 0.0;
+      s2[j] = 0.0;
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int row = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-          const float vv = o_pix[row] >= 0 ? acc[i][j][r] : 0.0f;
+          const double vv = o_pix[row] >= 0 ? (double)acc[i][j][r] : 0.0;
           s1[j] += vv;
-          s2[j] = fmaf(vv, vv, s2[j]);
+          s2[j] += vv * vv;
         }
       s1[j] += __shfl_xor(s1[j], 32);
       s2[j] += __shfl_xor(s2[j], 32);
     }
     __syncthreads();  // every wave is past its last LDS tile read
-    float* red = reinterpret_cast<float*>(smem);  // [WM][2][BN]
+    double* red = reinterpret_cast<double*>(smem);  // [WM][2][BN]
     if (h == 0) {
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
@@ -259,7 +261,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a, const
     }
     __syncthreads();
     if (tid < BN && n0 + tid < a.N) {
-      float t1 = 0.0f, t2 = 0.0f;
+      double t1 = 0.0, t2 = 0.0;
 #pragma unroll
       for (int w = 0; w < WM; ++w) {
         t1 += red[(w * 2 + 0) * BN + tid];

@@ -19,7 +19,7 @@ struct ConvArgs {
   const float* shift;   // per-N, nullable (folded BN shift, or conv bias when scale == null)
   const float* res;     // addend plane (residual / gradient accumulate), nullable; pixel map of `out`
   float* out;           // output plane base
-  float* stats;         // nullable: per-M-tile column sums [tiles_m][2][N] (train-mode BatchNorm)
+  double* stats;        // nullable: per-M-tile column sums [tiles_m][2][N] (train-mode BatchNorm)
   int B, LH, LW, M;     // M = B*LH*LW
   int a_Hp, a_Wp, a_cs, a_co, a_s, a_oy, a_ox;
   int Kc;               // A channels per tap, multiple of 32
@@ -92,6 +92,8 @@ hipError_t vy_launch_detect(const DetArgs& a, void* scratch, float* ids, float* 
 // (deterministic).  Used for BatchNorm statistics, BN-backward sums, bias gradients.
 hipError_t vy_launch_reduce_partials(const float* partials, int n_part, int n_cols, double* out,
                                      hipStream_t s);
+hipError_t vy_launch_reduce_partials_f64(const double* partials, int n_part, int n_cols, double* out,
+                                         hipStream_t s);
 
 hipError_t vy_launch_f64_to_f32(const double* src, float* dst, int n, hipStream_t s);
 
@@ -190,7 +192,7 @@ hipError_t vy_launch_stem_wgrad(const StemWgradArgs& a, hipStream_t s);
 
 // stem forward in training: raw conv -> z plane + per-block column sums [blocks][2][32]
 int vy_stem_blocks(int B, int H, int W);
-hipError_t vy_launch_stem_raw(const StemArgs& a, float* partials, hipStream_t s);
+hipError_t vy_launch_stem_raw(const StemArgs& a, double* partials, hipStream_t s);
 
 // ---- fused targets + loss + d(loss)/d(raw predictions)
 // yolo_target.py:173-205 (dynamic ignore mask), :226-281 (merge), gluoncv YOLOV3Loss (yolo3.py:1187)

@@ -112,7 +112,7 @@ size_t train_plan(vy_net* net, int b, int h, int w, bool commit) {
       sfl += 2 * (size_t)((c.cout + 63) & ~63);
       // partials: forward stats, backward sums
       const size_t tiles_m = (size_t)((M + 127) / 128);
-      size_t pf = c.is_stem ? (size_t)vy_stem_blocks(b, h, w) * 64 : tiles_m * 2 * c.cout;
+      size_t pf = 2 * (c.is_stem ? (size_t)vy_stem_blocks(b, h, w) * 64 : tiles_m * 2 * c.cout);  // doubles
       const size_t chunks = (size_t)((M + 2047) / 2048);
       if (chunks * 2 * c.cout > pf) pf = chunks * 2 * c.cout;
       if (c.is_stem) {
@@ -269,7 +269,7 @@ int forward_train(const TrainCtx& c, const float* x) {
       a.Cout = cv.cout;
       a.out_cs = zp.C;
       a.out_co = 0;
-      HIP_TRY(vy_launch_stem_raw(a, c.partials(), c.s));
+      HIP_TRY(vy_launch_stem_raw(a, reinterpret_cast<double*>(c.partials()), c.s));
       n_part = vy_stem_blocks(B, net->H, net->W);
     } else {
       ConvArgs a = net->conv_args(cv);
@@ -282,12 +282,13 @@ int forward_train(const TrainCtx& c, const float* x) {
       a.o_co = 0;
       a.o_s = 1;
       a.ups = 1;
-      a.stats = c.partials();
+      a.stats = reinterpret_cast<double*>(c.partials());
       HIP_TRY(vy_launch_conv_igemm(a, c.s));
       n_part = vy_conv_tiles_m(a);
     }
     const int C = cv.cout;
-    HIP_TRY(vy_launch_reduce_partials(c.partials(), n_part, 2 * C, c.sums_local(), c.s));
+    HIP_TRY(vy_launch_reduce_partials_f64(reinterpret_cast<const double*>(c.partials()), n_part, 2 * C,
+                                          c.sums_local(), c.s));
     double count = (double)B * zp.H * zp.W;
     if (int rc = combine_sums(c, cv, 2 * C, &count)) return rc;
     BnFinalizeArgs f;
@@ -737,6 +738,21 @@ int vy_net_grad_get(vy_net* net, int32_t i, float* host_dst, void* stream) {
     memcpy(host_dst, tmp.data(), sizeof(float) * pi.size);
   }
   return 0;
+}
+
+int vy_net_read_grad_activation(vy_net* net, const char* name, float* dst_dev, void* stream) {
+  if (!net || !name || !dst_dev) return fail(VY_ERR_INVALID, "bad argument");
+  if (int rc = net->check_ready()) return rc;
+  VyTrain* t = net->train;
+  if (!t || !t->grads) return fail(VY_ERR_STATE, "training workspace not bound");
+  TrainCtx c{net, t, static_cast<hipStream_t>(stream)};
+  for (const ConvT& cv : net->convs) {
+    if (cv.name != name) continue;
+    const PlaneT& p = net->planes[cv.out_plane];
+    HIP_TRY(vy_launch_plane_to_nchw(c.gplane(cv.out_plane), net->B, p.H, p.W, p.C, cv.out_co, cv.cout, dst_dev, c.s));
+    return 0;
+  }
+  return fail(VY_ERR_INVALID, "no cell named '%s'", name);
 }
 
 int vy_net_set_sync_bn(vy_net* net, int32_t world, vy_allreduce_cb cb, void* user) {

@@ -15,7 +15,8 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partials, int n_part,
+template <typename T>
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const T* __restrict__ partials, int n_part,
                                                               int n_cols, double* __restrict__ out) {
   // block = 32 columns x 8 row-groups
   __shared__ double red[8][33];
@@ -35,8 +36,15 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
 }
 
 hipError_t vy_launch_reduce_partials(const float* partials, int n_part, int n_cols, double* out, hipStream_t s) {
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3((n_cols + 31) / 32), dim3(256), 0, s, partials, n_part, n_cols,
-                     out);
+  hipLaunchKernelGGL(reduce_partials_kernel<float>, dim3((n_cols + 31) / 32), dim3(256), 0, s, partials, n_part,
+                     n_cols, out);
+  return hipGetLastError();
+}
+
+hipError_t vy_launch_reduce_partials_f64(const double* partials, int n_part, int n_cols, double* out,
+                                         hipStream_t s) {
+  hipLaunchKernelGGL(reduce_partials_kernel<double>, dim3((n_cols + 31) / 32), dim3(256), 0, s, partials, n_part,
+                     n_cols, out);
   return hipGetLastError();
 }
 
@@ -288,9 +296,9 @@ hipError_t vy_launch_colsum(const float* plane, int B, int H, int W, int cs, int
 // Stem in training: raw conv output + per-block channel sums.  Same thread mapping as stem_kernel.
 int vy_stem_blocks(int B, int H, int W) { return (int)(((long long)B * H * W + 255) / 256); }
 
-__global__ __launch_bounds__(256) void stem_raw_kernel(const StemArgs a, float* __restrict__ partials) {
+__global__ __launch_bounds__(256) void stem_raw_kernel(const StemArgs a, double* __restrict__ partials) {
   __shared__ float sw[32 * 27];
-  __shared__ float red[2][4][32];
+  __shared__ double red[2][4][32];
   for (int i = threadIdx.x; i < 32 * 27; i += 256) sw[i] = a.w[i];
   __syncthreads();
   const long long npix = (long long)a.B * a.H * a.W;
@@ -335,7 +343,7 @@ __global__ __launch_bounds__(256) void stem_raw_kernel(const StemArgs a, float* 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
   for (int c = 0; c < 32; ++c) {
-    float s1 = accs[c], s2 = accs[c] * accs[c];
+    double s1 = (double)accs[c], s2 = (double)accs[c] * (double)accs[c];
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
       s1 += __shfl_xor(s1, off);
@@ -349,12 +357,12 @@ __global__ __launch_bounds__(256) void stem_raw_kernel(const StemArgs a, float* 
   __syncthreads();
   if (threadIdx.x < 64) {
     const int which = threadIdx.x >> 5, c = threadIdx.x & 31;
-    const float s = (red[which][0][c] + red[which][1][c]) + (red[which][2][c] + red[which][3][c]);
+    const double s = (red[which][0][c] + red[which][1][c]) + (red[which][2][c] + red[which][3][c]);
     partials[(long long)blockIdx.x * 64 + which * 32 + c] = s;
   }
 }
 
-hipError_t vy_launch_stem_raw(const StemArgs& a, float* partials, hipStream_t s) {
+hipError_t vy_launch_stem_raw(const StemArgs& a, double* partials, hipStream_t s) {
   if (a.Cout != 32 || (a.out_cs & 3) || (a.out_co & 3)) return hipErrorInvalidValue;
   hipLaunchKernelGGL(stem_raw_kernel, dim3(vy_stem_blocks(a.B, a.H, a.W)), dim3(256), 0, s, a, partials);
   return hipGetLastError();

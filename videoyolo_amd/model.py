@@ -476,6 +476,18 @@ class YOLOV3(object):
                                                  self._stream()))
         return out
 
+    def read_grad_activation(self, name):
+        """d(loss)/d(output of cell `name`) after backward(), NCHW (parity tap)."""
+        torch = _torch()
+        c, h, w = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
+        _lib.check(self._lib.vy_net_read_activation(self._h, name.encode(), None, ctypes.byref(c),
+                                                    ctypes.byref(h), ctypes.byref(w), None))
+        out = torch.empty((self._plan[0], c.value, h.value, w.value), dtype=torch.float32, device=self._device)
+        with torch.cuda.device(self._device):
+            _lib.check(self._lib.vy_net_read_grad_activation(self._h, name.encode(),
+                                                             ctypes.c_void_p(out.data_ptr()), self._stream()))
+        return out
+
     def _sync_opts(self):
         for p in self._params.values():
             _lib.check(self._lib.vy_net_param_set_opt(self._h, p.index, float(p.lr_mult), float(p.wd_mult),
