@@ -41,7 +41,17 @@ def main():
                     help="added to the objectness biases (-5: trained-like sparse candidates)")
     ap.add_argument("--cpu-frames", type=int, default=4, help="frames of the CPU-oracle sample (0: skip)")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--mode", choices=["infer", "train"], default="infer",
+                    help="infer: BASELINE configs[1] (default); train: configs[2] (416x416, batch 16/GPU, "
+                         "fwd + bwd + gradient all-reduce + SGD)")
+    ap.add_argument("--syncbn", action="store_true", help="train: SyncBatchNorm statistics all-reduce (configs[4])")
+    ap.add_argument("--no-overlap", action="store_true", help="train: all-reduce after backward instead of bucketed")
     args = ap.parse_args()
+    if args.mode == "train":
+        if "--size" not in " ".join(sys.argv):
+            args.size = 416
+        if "--batch" not in " ".join(sys.argv):
+            args.batch = 16
 
     import numpy as np
     import torch
@@ -72,6 +82,9 @@ def main():
 
     g = torch.Generator(device="cpu").manual_seed(233 + rank)
     x = torch.randn((args.batch, 3, args.size, args.size), generator=g, dtype=torch.float32).to(dev)
+
+    if args.mode == "train":
+        return bench_train(args, vy, net, x, dev, dist, rank, world)
 
     def barrier():
         if dist is not None:
@@ -164,6 +177,89 @@ def main():
             "sample": "%d frames of the same %dx%d batch through oracle/ (C + OpenMP conv, numpy graph, "
                       "C NMS); MXNet itself is not installable here" % (args.cpu_frames, args.size, args.size)}
 
+    if rank == 0:
+        print(json.dumps(result))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def bench_train(args, vy, net, x, dev, dist, rank, world):
+    """BASELINE configs[2]/[4]: one step = recorded forward (batch-stat BN, targets, loss) + backward +
+    gradient all-reduce (RCCL, bucketed and overlapped with backward) + SGD update."""
+    import numpy as np
+    import torch
+    from videoyolo_amd import autograd, parallel, targets
+    gt_boxes, gt_ids = targets.synthetic_gt(args.batch, args.size, args.classes, m=8, seed=100 + rank)
+    tg = targets.YOLOV3PrefetchTargetGenerator(args.classes)(args.size, args.size, gt_boxes, gt_ids)
+    dv = [torch.as_tensor(t).to(dev) for t in (gt_boxes,) + tuple(tg)]
+    trainer = vy.Trainer(net.collect_params(), 'sgd', {'learning_rate': 1e-3, 'wd': 5e-4, 'momentum': 0.9})
+    if world > 1 and not args.no_overlap:
+        trainer.enable_overlap()
+    if args.syncbn and world > 1:
+        parallel.SyncBatchNormHook(net)
+    global_batch = args.batch * world
+
+    def step():
+        with autograd.record():
+            losses = net(x, *dv)
+            autograd.backward([losses[0] + losses[1] + losses[2] + losses[3]])
+        trainer.step(global_batch)
+        return losses
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        losses = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    fps = global_batch * args.steps / dt
+    fwd_gflop = {416: 65.43, 608: 139.76}.get(args.size)
+    result = {
+        "metric": "frames/sec, yolo3_darknet53 training %dx%d" % (args.size, args.size),
+        "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "BASELINE.json configs[%d]: training step, VOC-shape synthetic (%d cls, 8 gt/img), "
+                               "%dx%d, per-GPU batch %d, SGD(1e-3, 0.9, 5e-4), %s BN, gradient all-reduce over %d rank(s)"
+                               % (4 if args.syncbn else 2, args.classes, args.size, args.size, args.batch,
+                                  "Sync" if args.syncbn else "per-device", world),
+                   "per_gpu_batch": args.batch, "global_batch": global_batch, "size": args.size,
+                   "classes": args.classes, "parallelism": "dp%d" % world,
+                   "loss_rank0": float(sum(l.sum() for l in losses).item() / args.batch)},
+    }
+    if rank == 0 and not args.no_roofline and fwd_gflop:
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        fw, bw, up = [], [], []
+        for _ in range(3):
+            ev[0].record()
+            with autograd.record():
+                losses = net(x, *dv)
+                ev[1].record()
+                autograd.backward([losses[0]])
+            ev[2].record()
+            trainer.step(global_batch)
+            ev[3].record()
+            torch.cuda.synchronize()
+            fw.append(ev[0].elapsed_time(ev[1])); bw.append(ev[1].elapsed_time(ev[2])); up.append(ev[2].elapsed_time(ev[3]))
+        fw, bw, up = sorted(fw)[1], sorted(bw)[1], sorted(up)[1]
+        fl = fwd_gflop * 1e9 * args.batch
+        result["roofline"] = {
+            "bound": "mfma", "achieved": 3 * fl / ((fw + bw) * 1e-3) / 1e12, "peak": FP32_MFMA_PEAK_TFLOPS,
+            "unit": "TFLOP/s", "frac": 3 * fl / ((fw + bw) * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+            "kernel": "training step: conv_igemm (forward + dgrad) and wgrad_kernel; algorithmic FLOPs = 3 x forward",
+            "forward_ms": fw, "backward_ms": bw, "allreduce_sgd_ms": up,
+            "forward_tflops": fl / (fw * 1e-3) / 1e12, "backward_tflops": 2 * fl / (bw * 1e-3) / 1e12}
     if rank == 0:
         print(json.dumps(result))
     if dist is not None:

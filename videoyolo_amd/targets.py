@@ -1,0 +1,93 @@
+"""Prefetch target generation — the CPU-side stage that builds the five fixed target tensors the
+training call consumes.
+
+Host-side mirror of ``YOLOV3PrefetchTargetGenerator`` (models/definitions/yolo/yolo_target.py:13-148),
+which the reference runs in DataLoader worker processes (train_yolov3.py:260-271,
+models/definitions/yolo/transforms.py:185-197,259-277).  Same host language (Python/numpy), but
+vectorised over the batch and the gt boxes instead of the reference's Python double loop; the
+quirks that decide the numbers are kept: centre -> cell by int() truncation (:115-116),
+log(max(w,1)/anchor) (:121-122), weight 2 - w*h/(W*H) (:123), later gt boxes overwrite earlier ones
+in the same (cell, anchor) slot, and rows after the first invalid (-1) gt box are ignored (:107-108).
+"""
+import numpy as np
+
+ANCHORS = np.array([[116, 90], [156, 198], [373, 326], [30, 61], [62, 45], [59, 119],
+                    [10, 13], [16, 30], [33, 23]], np.float32)  # stride 32, 16, 8 (wrappers.py:80-84 reversed)
+STRIDES = (32, 16, 8)
+
+
+def num_anchors(height, width):
+    return sum(3 * (height // s) * (width // s) for s in STRIDES)
+
+
+class YOLOV3PrefetchTargetGenerator(object):
+    def __init__(self, num_class):
+        self._num_class = num_class
+
+    def __call__(self, height, width, gt_boxes, gt_ids, gt_mixratio=None):
+        """gt_boxes (B,M,4) corner pixels, gt_ids (B,M,1), -1 rows = padding.
+        Returns objectness (B,N,1), center_targets (B,N,2), scale_targets (B,N,2), weights (B,N,2),
+        class_targets (B,N,C) in the order the training forward expects (stride 32,16,8; cell; anchor)."""
+        gt_boxes = np.asarray(gt_boxes, np.float32)
+        gt_ids = np.asarray(gt_ids, np.float32)
+        B, M = gt_boxes.shape[:2]
+        C = self._num_class
+        N = num_anchors(height, width)
+        obj = np.zeros((B, N, 1), np.float32)
+        ctr = np.zeros((B, N, 2), np.float32)
+        scl = np.zeros((B, N, 2), np.float32)
+        wts = np.zeros((B, N, 2), np.float32)
+        cls = np.full((B, N, C), -1, np.float32)
+        if M == 0:
+            return obj, ctr, scl, wts, cls
+        gtw = gt_boxes[..., 2] - gt_boxes[..., 0]
+        gth = gt_boxes[..., 3] - gt_boxes[..., 1]
+        gtx = (gt_boxes[..., 0] + gt_boxes[..., 2]) / 2
+        gty = (gt_boxes[..., 1] + gt_boxes[..., 3]) / 2
+        # best anchor by IoU of zero-centred boxes: inter = min(w)*min(h) (both centred at 0)
+        iw = np.minimum(gtw[..., None], ANCHORS[:, 0])
+        ih = np.minimum(gth[..., None], ANCHORS[:, 1])
+        inter = np.clip(iw, 0, None) * np.clip(ih, 0, None)
+        union = gtw[..., None] * gth[..., None] + ANCHORS[:, 0] * ANCHORS[:, 1] - inter
+        iou = np.where(union > 0, inter / np.where(union > 0, union, 1), 0)
+        match = iou.argmax(axis=-1)  # (B,M)
+        valid = (gt_boxes >= 0).all(axis=-1)
+        valid = np.logical_and.accumulate(valid, axis=1)  # stop at the first invalid row
+        layer = match // 3
+        stride = np.array(STRIDES)[layer]
+        fw, fh = width // stride, height // stride
+        # float64 division then truncation, as Python's int(gtx / orig_width * width) does
+        fx = gtx.astype(np.float32) / np.float32(width) * fw.astype(np.float32)
+        fy = gty.astype(np.float32) / np.float32(height) * fh.astype(np.float32)
+        loc_x, loc_y = fx.astype(np.int64), fy.astype(np.int64)
+        cells = np.array([0] + list(np.cumsum([(height // s) * (width // s) for s in STRIDES])))[:-1]
+        base = np.array([0] + list(np.cumsum([3 * (height // s) * (width // s) for s in STRIDES])))[:-1]
+        n_idx = base[layer] + (loc_y * fw + loc_x) * 3 + (match % 3)
+        del cells
+        anc = ANCHORS[match]
+        for b in range(B):  # in-order assignment so later boxes overwrite earlier ones
+            for m in np.nonzero(valid[b])[0]:
+                n = n_idx[b, m]
+                ctr[b, n, 0] = fx[b, m] - loc_x[b, m]
+                ctr[b, n, 1] = fy[b, m] - loc_y[b, m]
+                scl[b, n, 0] = np.log(max(gtw[b, m], 1) / anc[b, m, 0])
+                scl[b, n, 1] = np.log(max(gth[b, m], 1) / anc[b, m, 1])
+                wts[b, n, :] = 2.0 - gtw[b, m] * gth[b, m] / width / height
+                obj[b, n, 0] = gt_mixratio[b, m, 0] if gt_mixratio is not None else 1
+                cls[b, n, :] = 0
+                cls[b, n, int(gt_ids[b, m, 0])] = 1
+        return obj, ctr, scl, wts, cls
+
+
+def synthetic_gt(batch, size, num_class, m=8, seed=0):
+    """M gt boxes / image, uniform centres, w,h ~ U(32,256) clipped to the image
+    (scaled for small images), class ~ U{0..C-1}."""
+    rng = np.random.default_rng(seed)
+    lo, hi = (32, 256) if size >= 320 else (size / 8, size / 1.5)
+    c = rng.uniform(0, size, (batch, m, 2))
+    wh = rng.uniform(lo, hi, (batch, m, 2))
+    x1y1 = np.clip(c - wh / 2, 0, size - 2)
+    x2y2 = np.clip(c + wh / 2, x1y1 + 1, size - 1)
+    boxes = np.concatenate([x1y1, x2y2], -1).astype(np.float32)
+    ids = rng.integers(0, num_class, (batch, m, 1)).astype(np.float32)
+    return boxes, ids
