@@ -286,12 +286,42 @@ static hipError_t launch_cfg(const ConvArgs& a, hipStream_t s) {
   return hipGetLastError();
 }
 
-int vy_conv_tiles_m(const ConvArgs& a) { return (a.M + 127) / 128; }
+// Tile choice: the 128x128 tile has the best arithmetic intensity, but a launch needs >= ~2 blocks
+// per CU slot (256 CUs x 2 resident blocks) to fill the chip; small-M layers (13x13 and 26x26 maps
+// at batch 16) and the narrow-N dgrads fall back to 128x64 and then 64x64 tiles.
+static void select_cfg(const ConvArgs& a, int* bm, int* bn) {
+  auto blocks = [&](int m, int n) { return (long long)((a.M + m - 1) / m) * ((a.N + n - 1) / n); };
+  if (a.N <= 32) {
+    *bm = 128;
+    *bn = 32;
+    return;
+  }
+  const long long want = 1024;
+  if (a.N > 64 && blocks(128, 128) >= want) {
+    *bm = 128;
+    *bn = 128;
+  } else if (blocks(128, 64) >= want || a.M <= 64) {
+    *bm = 128;
+    *bn = 64;
+  } else {
+    *bm = 64;
+    *bn = 64;
+  }
+}
+
+int vy_conv_tiles_m(const ConvArgs& a) {
+  int bm, bn;
+  select_cfg(a, &bm, &bn);
+  return (a.M + bm - 1) / bm;
+}
 
 hipError_t vy_launch_conv_igemm(const ConvArgs& a, hipStream_t s) {
   if (a.Kc % 32 != 0 || a.ntaps < 1 || a.ntaps > 9 || a.M <= 0 || a.N <= 0) return hipErrorInvalidValue;
   if (a.dgrad && (a.N % 4 != 0)) return hipErrorInvalidValue;
-  if (a.N <= 32) return launch_cfg<128, 32, 4, 1>(a, s);
-  if (a.N <= 64) return launch_cfg<128, 64, 2, 2>(a, s);
+  int bm, bn;
+  select_cfg(a, &bm, &bn);
+  if (bn == 32) return launch_cfg<128, 32, 4, 1>(a, s);
+  if (bm == 128 && bn == 64) return launch_cfg<128, 64, 2, 2>(a, s);
+  if (bm == 64) return launch_cfg<64, 64, 2, 2>(a, s);
   return launch_cfg<128, 128, 2, 2>(a, s);
 }

@@ -65,6 +65,8 @@ namespace {
 
 size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 
+constexpr int kBwdChunk = 64;  // pixels per partial-sum block of the BN-backward / bias-gradient reductions
+
 bool is_sync_layer(const ConvT& c) {
   // the layers Darknet3D builds with the passed norm_layer: the stem and the stride-2 convs
   // (three_darknet.py:163-181); every other BatchNorm in the model is a plain per-device one
@@ -113,7 +115,7 @@ size_t train_plan(vy_net* net, int b, int h, int w, bool commit) {
       // partials: forward stats, backward sums
       const size_t tiles_m = (size_t)((M + 127) / 128);
       size_t pf = 2 * (c.is_stem ? (size_t)vy_stem_blocks(b, h, w) * 64 : tiles_m * 2 * c.cout);  // doubles
-      const size_t chunks = (size_t)((M + 2047) / 2048);
+      const size_t chunks = (size_t)((M + kBwdChunk - 1) / kBwdChunk);
       if (chunks * 2 * c.cout > pf) pf = chunks * 2 * c.cout;
       if (c.is_stem) {
         const size_t sw = (size_t)vy_stem_wgrad_blocks(b, h, w) * 864;
@@ -121,7 +123,7 @@ size_t train_plan(vy_net* net, int b, int h, int w, bool commit) {
       }
       if (pf > part) part = pf;
     } else {
-      const size_t chunks = (size_t)((M + 2047) / 2048);
+      const size_t chunks = (size_t)((M + kBwdChunk - 1) / kBwdChunk);
       if (chunks * c.cout > part) part = chunks * c.cout;
     }
     if (!c.is_stem) {
@@ -233,14 +235,16 @@ struct TrainCtx {
   float* grad_of(int pidx) const { return t->grads + net->params[pidx].info.offset; }
 };
 
-// sums_local -> sums_global (+ all-reduce over ranks for the SyncBN layers)
-int combine_sums(const TrainCtx& c, const ConvT& cv, int n_cols, double* count) {
-  HIP_TRY(hipMemcpyAsync(c.sums_global(), c.sums_local(), sizeof(double) * n_cols, hipMemcpyDeviceToDevice, c.s));
+// the sums the normalisation uses: the local ones, or (SyncBN layers, world > 1) their all-reduce
+int combine_sums(const TrainCtx& c, const ConvT& cv, int n_cols, double* count, const double** use) {
+  *use = c.sums_local();
   if (c.t->world > 1 && is_sync_layer(cv)) {
     if (!c.t->ar_cb) return fail(VY_ERR_STATE, "SyncBN world > 1 without an all-reduce callback");
+    HIP_TRY(hipMemcpyAsync(c.sums_global(), c.sums_local(), sizeof(double) * n_cols, hipMemcpyDeviceToDevice, c.s));
     if (int rc = c.t->ar_cb(c.t->ar_user, c.sums_global(), n_cols))
       return fail(VY_ERR_STATE, "all-reduce callback failed (%d)", rc);
     *count *= c.t->world;
+    *use = c.sums_global();
   }
   return 0;
 }
@@ -290,9 +294,10 @@ int forward_train(const TrainCtx& c, const float* x) {
     HIP_TRY(vy_launch_reduce_partials_f64(reinterpret_cast<const double*>(c.partials()), n_part, 2 * C,
                                           c.sums_local(), c.s));
     double count = (double)B * zp.H * zp.W;
-    if (int rc = combine_sums(c, cv, 2 * C, &count)) return rc;
+    const double* use_sums;
+    if (int rc = combine_sums(c, cv, 2 * C, &count, &use_sums)) return rc;
     BnFinalizeArgs f;
-    f.sums = c.sums_global();
+    f.sums = use_sums;
     f.count = count;
     f.gamma = net->dev_params + net->params[cv.p_gamma].info.offset;
     f.beta = net->dev_params + net->params[cv.p_beta].info.offset;
@@ -496,8 +501,8 @@ int backward_train(const TrainCtx& c, const float* x) {
       dz_cs = pp.C;
       dzH = pp.H;
       dzW = pp.W;
-      const int chunks = vy_colsum_chunks(B, pp.H, pp.W, 2048);
-      HIP_TRY(vy_launch_colsum(dzp, B, pp.H, pp.W, pp.C, 0, cv.cout, 2048, c.partials(), c.s));
+      const int chunks = vy_colsum_chunks(B, pp.H, pp.W, kBwdChunk);
+      HIP_TRY(vy_launch_colsum(dzp, B, pp.H, pp.W, pp.C, 0, cv.cout, kBwdChunk, c.partials(), c.s));
       HIP_TRY(vy_launch_reduce_partials(c.partials(), chunks, cv.cout, c.sums_local(), c.s));
       HIP_TRY(vy_launch_f64_to_f32(c.sums_local(), c.grad_of(cv.p_bias), cv.cout, c.s));
     } else {
@@ -524,14 +529,15 @@ int backward_train(const TrainCtx& c, const float* x) {
       bb.g_cs = op.C;
       bb.g_co = cv.out_co;
       bb.ups = cv.ups;
-      bb.chunk = 2048;
+      bb.chunk = kBwdChunk;
       HIP_TRY(vy_launch_bn_bwd_reduce(bb, c.s));
       HIP_TRY(vy_launch_reduce_partials(c.partials(), vy_bn_bwd_chunks(bb), 2 * cv.cout, c.sums_local(), c.s));
       double count = (double)B * zp.H * zp.W;
-      if (int rc = combine_sums(c, cv, 2 * cv.cout, &count)) return rc;
+      const double* use_sums;
+      if (int rc = combine_sums(c, cv, 2 * cv.cout, &count, &use_sums)) return rc;
       BnBwdFinalizeArgs f;
       memset(&f, 0, sizeof f);
-      f.sums = c.sums_global();
+      f.sums = use_sums;
       f.local_sums = c.sums_local();
       f.count = count;
       f.gamma = net->dev_params + net->params[cv.p_gamma].info.offset;

@@ -16,34 +16,35 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // ------------------------------------------------------------------------------------------------
 template <typename T>
-__global__ __launch_bounds__(256) void reduce_partials_kernel(const T* __restrict__ partials, int n_part,
-                                                              int n_cols, double* __restrict__ out) {
-  // block = 32 columns x 8 row-groups
-  __shared__ double red[8][33];
+__global__ __launch_bounds__(1024) void reduce_partials_kernel(const T* __restrict__ partials, int n_part,
+                                                               int n_cols, double* __restrict__ out) {
+  // block = 32 columns x 32 row-groups; row-group r sums partials r, r+32, ... in order, then the 32
+  // group sums are added in order: a fixed summation tree (deterministic)
+  __shared__ double red[32][33];
   const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
   const int c = blockIdx.x * 32 + cx;
   double acc = 0.0;
   if (c < n_cols)
-    for (int t = ry; t < n_part; t += 8) acc += (double)partials[(long long)t * n_cols + c];
+    for (int t = ry; t < n_part; t += 32) acc += (double)partials[(long long)t * n_cols + c];
   red[ry][cx] = acc;
   __syncthreads();
   if (ry == 0 && c < n_cols) {
     double s = 0.0;
 #pragma unroll
-    for (int r = 0; r < 8; ++r) s += red[r][cx];
+    for (int r = 0; r < 32; ++r) s += red[r][cx];
     out[c] = s;
   }
 }
 
 hipError_t vy_launch_reduce_partials(const float* partials, int n_part, int n_cols, double* out, hipStream_t s) {
-  hipLaunchKernelGGL(reduce_partials_kernel<float>, dim3((n_cols + 31) / 32), dim3(256), 0, s, partials, n_part,
+  hipLaunchKernelGGL(reduce_partials_kernel<float>, dim3((n_cols + 31) / 32), dim3(1024), 0, s, partials, n_part,
                      n_cols, out);
   return hipGetLastError();
 }
 
 hipError_t vy_launch_reduce_partials_f64(const double* partials, int n_part, int n_cols, double* out,
                                          hipStream_t s) {
-  hipLaunchKernelGGL(reduce_partials_kernel<double>, dim3((n_cols + 31) / 32), dim3(256), 0, s, partials, n_part,
+  hipLaunchKernelGGL(reduce_partials_kernel<double>, dim3((n_cols + 31) / 32), dim3(1024), 0, s, partials, n_part,
                      n_cols, out);
   return hipGetLastError();
 }
