@@ -127,17 +127,12 @@ def main():
         for j in range(len(names)):
             ms = sorted(p[j][1] for p in passes)[1]
             med.append((names[j], ms, passes[0][j][2], passes[0][j][3]))
-        pinfo = {p.name: p for p in net.collect_params().values()}
-
-        def variant(name):
-            w = pinfo.get(name + ".0.weight") or pinfo.get(name + ".weight")
-            if w is None or w.shape[1] == 3:
-                return None
-            return "128x32" if w.shape[0] <= 32 else ("128x64" if w.shape[0] <= 64 else "128x128")
         agg = {}
         for name, ms, fl, by in med:
-            v = variant(name)
-            key = ("conv_igemm_kernel<%s>" % v) if v else ("stem_kernel" if name == "stages.0.0" else name)
+            if "|" in name:  # conv launches are reported as "<cell>|<BM>x<BN>"
+                key = "conv_igemm_kernel<%s>" % name.split("|")[1]
+            else:
+                key = "stem_kernel" if name == "stages.0.0" else name
             a = agg.setdefault(key, [0, 0.0, 0.0, 0.0])
             a[0] += 1
             a[1] += ms

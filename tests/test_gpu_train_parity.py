@@ -112,3 +112,46 @@ def test_train_options_and_inference_after_training():
     ids, scores, bboxes, keep = [t.cpu().numpy() for t in net(x, return_index=True)]
     r = O.OracleYolo3(C, newp)(x)
     assert np.array_equal(keep, r[3]) and np.array_equal(ids, r[0])
+
+
+def test_syncbn_plumbing_with_simulated_ranks():
+    """SyncBatchNorm path on one GPU: the statistics callback is driven with a stand-in for the RCCL
+    all-reduce that doubles the [2][C] sums, i.e. two ranks holding the same frames.  Batch mean and
+    variance are then unchanged, so losses and gradients must equal the per-device-BN run exactly;
+    the callback must fire for the 6 SyncBN layers, forward and backward (12 calls)."""
+    import torch
+    import videoyolo_amd as vy
+    from videoyolo_amd import _lib, autograd
+    C, B, S = 3, 2, 64
+    params, x, gt_boxes, tg = _setup(C, B, S, seed=9)
+
+    def run(sync):
+        net = _net(C, params)
+        calls = []
+        if sync:
+            def cb(user, ptr, count):
+                off = int(ptr) - net._ws.data_ptr()
+                view = net._ws[off:off + 8 * count].view(torch.float64)
+                view.mul_(2.0)
+                calls.append(int(count))
+                return 0
+            keep = _lib.ALLREDUCE_CB(cb)
+            net._cb_keep.append(keep)
+            with autograd.record():      # plan + bind first: the callback needs the workspace
+                net(x, gt_boxes, *tg)
+            autograd._get().tape = []
+            _lib.check(net._lib.vy_net_set_sync_bn(net._h, 2, keep, None))
+        with autograd.record():
+            losses = net(x, gt_boxes, *tg)
+            autograd.backward([sum(losses)])
+        grads = {n: net.grad(n) for n in ("stages.0.0.0.weight", "stages.0.1.1.gamma", "stages.1.0.1.beta",
+                                          "stages.2.0.0.weight", "yolo_blocks.0.body.0.0.weight")}
+        return [l.cpu().numpy() for l in losses], grads, calls
+
+    l0, g0, _ = run(False)
+    l1, g1, calls = run(True)
+    assert len(calls) == 12 and sorted(set(calls)) == [64, 128, 256, 512, 1024, 2048]
+    for a, b in zip(l0, l1):
+        assert np.array_equal(a, b)
+    for k in g0:
+        np.testing.assert_allclose(g1[k], g0[k], rtol=1e-5, atol=1e-7)

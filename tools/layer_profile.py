@@ -20,15 +20,15 @@ for _ in range(2):
     net(x)
 passes = [net.profile(x) for _ in range(3)]
 pinfo = {p.name: p for p in net.collect_params().values()}
-lines = ["%-26s %-18s %9s %9s %8s %8s" % ("launch", "w(O,I,k,k)", "ms", "GFLOP", "TFLOP/s", "GB/s")]
+lines = ["%-34s %-18s %9s %9s %8s %8s" % ("launch", "w(O,I,k,k)", "ms", "GFLOP", "TFLOP/s", "GB/s")]
 tot_ms = tot_fl = 0
 for j, (name, _, fl, by) in enumerate(passes[0]):
     ms = sorted(p[j][1] for p in passes)[1]
-    w = pinfo.get(name + ".0.weight") or pinfo.get(name + ".weight")
+    w = pinfo.get(name.split("|")[0] + ".0.weight") or pinfo.get(name.split("|")[0] + ".weight")
     shp = "x".join(map(str, w.shape)) if w is not None else "-"
-    lines.append("%-26s %-18s %9.4f %9.2f %8.1f %8.0f" % (name, shp, ms, fl / 1e9, fl / ms / 1e9 if ms else 0, by / ms / 1e6 if ms else 0))
+    lines.append("%-34s %-18s %9.4f %9.2f %8.1f %8.0f" % (name, shp, ms, fl / 1e9, fl / ms / 1e9 if ms else 0, by / ms / 1e6 if ms else 0))
     tot_ms += ms; tot_fl += fl
-lines.append("%-26s %-18s %9.4f %9.2f %8.1f" % ("TOTAL", "", tot_ms, tot_fl / 1e9, tot_fl / tot_ms / 1e9))
+lines.append("%-34s %-18s %9.4f %9.2f %8.1f" % ("TOTAL", "", tot_ms, tot_fl / 1e9, tot_fl / tot_ms / 1e9))
 lines.append("frames/s (sum of launches): %.1f" % (a.batch / tot_ms * 1e3))
 txt = "\n".join(lines)
 print(txt)

@@ -309,6 +309,8 @@ static void select_cfg(const ConvArgs& a, int* bm, int* bn) {
   }
 }
 
+void vy_conv_cfg(const ConvArgs& a, int* bm, int* bn) { select_cfg(a, bm, bn); }
+
 int vy_conv_tiles_m(const ConvArgs& a) {
   int bm, bn;
   select_cfg(a, &bm, &bn);

@@ -410,9 +410,13 @@ struct vy_net {
         const double fl = 2.0 * a.M * (double)a.N * a.ntaps * a.Kc;
         const double by = 4.0 * ((double)B * (a.a_Hp - 2) * (a.a_Wp - 2) * a.Kc + (double)a.M * a.N * a.ups * a.ups +
                                  (double)a.N * a.ntaps * a.Kc + (a.res ? (double)a.M * a.N : 0.0));
-        hook(c.name.c_str(), fl, by, true);
+        int bm, bn;
+        vy_conv_cfg(a, &bm, &bn);
+        char nm[96];
+        snprintf(nm, sizeof nm, "%s|%dx%d", c.name.c_str(), bm, bn);
+        hook(nm, fl, by, true);
         HIP_TRY(vy_launch_conv_igemm(a, s));
-        hook(c.name.c_str(), fl, by, false);
+        hook(nm, fl, by, false);
       }
     }
     const DetArgs d = det_args();
