@@ -29,11 +29,14 @@
 // 128x128 tile: 64 KiB of LDS -> 2 blocks / CU, 64 accumulator VGPRs / lane.
 // dgrad reads W as the [k][n] operand: its LDS tile is 32 k-rows of BN contiguous floats, read with
 // ds_read_b32 (32 consecutive floats per half-wave: conflict-free without a swizzle).
+#include <cstdlib>
+
 #include "kernels.h"
 #include "../../include/vy_math.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 
@@ -151,44 +154,55 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a, const
   for (int t = 0; t < T; ++t) {
     // tile t has landed (own DMA waited, then everyone's via the barrier) and every wave is done
     // reading the other buffer (it computed tile t-1 before arriving here)
-    __syncthreads();
-    if (t + 1 < T) stage(t + 1, (t + 1) & 1);
+    if (!(a.debug & 2)) __syncthreads();
+    if (t + 1 < T && !(a.debug & 1)) stage(t + 1, (t + 1) & 1);
     const unsigned char* sA = smem + (t & 1) * STAGE;
     const unsigned char* sB = sA + A_BYTES;
+    // Per 8-k group: the lower half-wave reads 16-B chunk 2g (k0..k3 of the group), the upper half
+    // chunk 2g+1 (k4..k7) — no redundant LDS bytes — then two v_permlane32_swap exchange the odd
+    // registers of the lower half with the even registers of the upper half, which leaves
+    //   lower: r0=k0 r1=k4 r2=k2 r3=k6      upper: r0=k1 r1=k5 r2=k3 r3=k7
+    // so the MFMA steps r0, r2, r1, r3 consume (k0,k1), (k2,k3), (k4,k5), (k6,k7): k ascending.
 #pragma unroll
-    for (int kk = 0; kk < 8; ++kk) {
-      float alo[TM], ahi[TM], blo[TN], bhi[TN];
+    for (int g = 0; g < 4; ++g) {
+      float af[TM][4], bf[TN][4];
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
         const int row = (wm * TM + i) * 32 + lrow;
-        const f32x4 q = *reinterpret_cast<const f32x4*>(sA + row * 128 + ((kk ^ ((row >> 1) & 7)) << 4));
-        alo[i] = h ? q[1] : q[0];
-        ahi[i] = h ? q[3] : q[2];
+        const f32x4 q = *reinterpret_cast<const f32x4*>(sA + row * 128 + (((2 * g + h) ^ ((row >> 1) & 7)) << 4));
+        const u32x2 s01 = __builtin_amdgcn_permlane32_swap(__float_as_uint(q[0]), __float_as_uint(q[1]), false, false);
+        const u32x2 s23 = __builtin_amdgcn_permlane32_swap(__float_as_uint(q[2]), __float_as_uint(q[3]), false, false);
+        af[i][0] = __uint_as_float(s01[0]);
+        af[i][2] = __uint_as_float(s01[1]);
+        af[i][1] = __uint_as_float(s23[0]);
+        af[i][3] = __uint_as_float(s23[1]);
       }
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         if (!DGRAD) {
           const int row = (wn * TN + j) * 32 + lrow;
-          const f32x4 q = *reinterpret_cast<const f32x4*>(sB + row * 128 + ((kk ^ ((row >> 1) & 7)) << 4));
-          blo[j] = h ? q[1] : q[0];
-          bhi[j] = h ? q[3] : q[2];
+          const f32x4 q = *reinterpret_cast<const f32x4*>(sB + row * 128 + (((2 * g + h) ^ ((row >> 1) & 7)) << 4));
+          const u32x2 s01 = __builtin_amdgcn_permlane32_swap(__float_as_uint(q[0]), __float_as_uint(q[1]), false, false);
+          const u32x2 s23 = __builtin_amdgcn_permlane32_swap(__float_as_uint(q[2]), __float_as_uint(q[3]), false, false);
+          bf[j][0] = __uint_as_float(s01[0]);
+          bf[j][2] = __uint_as_float(s01[1]);
+          bf[j][1] = __uint_as_float(s23[0]);
+          bf[j][3] = __uint_as_float(s23[1]);
         } else {
           const int col = (wn * TN + j) * 32 + lrow;
           const float* tb = reinterpret_cast<const float*>(sB);
-          blo[j] = tb[(kk * 4 + h) * BN + col];
-          bhi[j] = tb[(kk * 4 + 2 + h) * BN + col];
+#pragma unroll
+          for (int st = 0; st < 4; ++st) bf[j][st] = tb[(g * 8 + 2 * st + h) * BN + col];
         }
       }
+      // af/bf[.][st] now hold MFMA step st of this group (k = 8g + 2st + h)
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
+      for (int st = 0; st < 4; ++st)
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(alo[i], blo[j], acc[i][j], 0, 0, 0);
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ahi[i], bhi[j], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][st], bf[j][st], acc[i][j], 0, 0, 0);
     }
   }
 
@@ -317,7 +331,12 @@ int vy_conv_tiles_m(const ConvArgs& a) {
   return (a.M + bm - 1) / bm;
 }
 
-hipError_t vy_launch_conv_igemm(const ConvArgs& a, hipStream_t s) {
+hipError_t vy_launch_conv_igemm(const ConvArgs& a_in, hipStream_t s) {
+  // timing experiments only (results are wrong): VY_DEBUG_CONV bit0 = skip the LDS-DMA of tiles > 0,
+  // bit1 = skip the per-k-step barrier
+  static const int dbg = getenv("VY_DEBUG_CONV") ? atoi(getenv("VY_DEBUG_CONV")) : 0;
+  ConvArgs a = a_in;
+  a.debug = dbg;
   if (a.Kc % 32 != 0 || a.ntaps < 1 || a.ntaps > 9 || a.M <= 0 || a.N <= 0) return hipErrorInvalidValue;
   if (a.dgrad && (a.N % 4 != 0)) return hipErrorInvalidValue;
   int bm, bn;

@@ -33,6 +33,7 @@ struct ConvArgs {
   int r_cs, r_co;
   int leaky;            // LeakyReLU(0.1) after the affine
   int dgrad;            // 0: W is the [n][k] operand (forward); 1: W is the [k][n] operand (dgrad)
+  int debug;            // timing experiments (VY_DEBUG_CONV); 0 in production
 };
 
 // 3x3/1x1 implicit-GEMM convolution on v_mfma_f32_32x32x2_f32.
