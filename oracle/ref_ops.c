@@ -15,8 +15,14 @@
  * Layouts are the reference's: activations NCHW, conv weights OIHW, fp32 everywhere.
  *
  * Summation order (documented because the HIP kernels are held to bit-equality with it):
- *   conv accumulates ONE fp32 fma chain per output element, starting from +0, over
- *   k = (kh, kw, cin) with kh outermost and cin innermost; bias/BN/activation follow.
+ *   conv accumulates ONE fp32 fma chain per output element, starting from +0, over taps (kh, kw)
+ *   with kh outermost and, inside a tap, over the input channels; when Cin is a multiple of 8 the
+ *   channels of each aligned group of 8 are visited in the order 0,4,1,5,2,6,3,7 (the order in
+ *   which the fp32 matrix instruction of the device consumes a 32-byte channel group: its two
+ *   half-waves hold channels 0-3 and 4-7 and alternate), otherwise (the 3-channel stem) ascending.
+ *   A dot product's summation order is not part of the reference's definition (mxnet delegates it to
+ *   MKL-DNN / cuDNN); fixing one order on both sides is what makes bit-equality testable.
+ *   Bias/BN/activation follow.
  */
 #include <math.h>
 #include <stdint.h>
@@ -64,7 +70,9 @@ void vyo_conv2d(const float* x, int N, int C, int H, int W, const float* w, int 
               int lo = 0, hi = Wo;
               while (lo < Wo && lo * s + kw - p < 0) ++lo;
               while (hi > lo && (hi - 1) * s + kw - p >= W) --hi;
-              for (int c = 0; c < C; ++c) {
+              for (int cc = 0; cc < C; ++cc) {
+                /* channel visiting order, see the header: 0,4,1,5,2,6,3,7 per group of 8 */
+                const int c = (C % 8 == 0) ? ((cc & ~7) | (((cc & 1) << 2) | ((cc & 7) >> 1))) : cc;
                 const float wv = w[(((size_t)o * C + c) * k + kh) * k + kw];
                 const float* xr = x + (((size_t)n * C + c) * H + iy) * W + (kw - p);
 #pragma omp simd

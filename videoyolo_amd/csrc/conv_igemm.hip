@@ -18,9 +18,11 @@
 // pixel m for tap t is 32 contiguous floats at a fixed offset from the pixel's centre address.
 //
 // Numerics: v_mfma_f32_32x32x2_f32 is an exact fp32 fma chain in k order (k0 from lanes 0-31, k1
-// from lanes 32-63).  Each lane fetches 4 consecutive k with one ds_read_b128 and the two lane
-// halves pick (k0|k1) and (k2|k3), so every output element is ONE fma chain over k ascending —
-// the same order the CPU checker uses, which makes the conv stack bit-reproducible.
+// from lanes 32-63).  Each lane fetches 4 consecutive channels with one ds_read_b128; the lower
+// half-wave takes channels 8g..8g+3 and the upper half 8g+4..8g+7 of each group of 8, so every
+// output element is ONE fma chain over taps (kh,kw) ascending and, inside a tap, channels in the
+// order 0,4,1,5,2,6,3,7 per aligned group of 8 — the order the CPU checker uses too, which makes
+// the conv stack bit-reproducible with zero cross-lane traffic.
 //
 // Tiling (MI355X): 256 threads = 4 waves; block tile 128 x BN x 32(k); per k-step the A and W
 // tiles (128 B per row) are brought in by LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave
@@ -158,51 +160,39 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a, const
     if (t + 1 < T && !(a.debug & 1)) stage(t + 1, (t + 1) & 1);
     const unsigned char* sA = smem + (t & 1) * STAGE;
     const unsigned char* sB = sA + A_BYTES;
-    // Per 8-k group: the lower half-wave reads 16-B chunk 2g (k0..k3 of the group), the upper half
-    // chunk 2g+1 (k4..k7) — no redundant LDS bytes — then two v_permlane32_swap exchange the odd
-    // registers of the lower half with the even registers of the upper half, which leaves
-    //   lower: r0=k0 r1=k4 r2=k2 r3=k6      upper: r0=k1 r1=k5 r2=k3 r3=k7
-    // so the MFMA steps r0, r2, r1, r3 consume (k0,k1), (k2,k3), (k4,k5), (k6,k7): k ascending.
+    // Per 8-k group g: the lower half-wave reads 16-B chunk 2g (channels 8g..8g+3), the upper half
+    // chunk 2g+1 (channels 8g+4..8g+7) — every LDS byte is read once, no cross-lane movement.  MFMA
+    // step j of the group then multiplies channel 8g+j (lanes 0-31, the k0 slot) and 8g+4+j (lanes
+    // 32-63, the k1 slot): within a group of 8 the fma chain visits channels 0,4,1,5,2,6,3,7.  That
+    // IS the summation order of this framework (the CPU checker walks the same order).
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      float af[TM][4], bf[TN][4];
+      f32x4 af[TM], bf[TN];
+      float bs[TN][4];
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
         const int row = (wm * TM + i) * 32 + lrow;
-        const f32x4 q = *reinterpret_cast<const f32x4*>(sA + row * 128 + (((2 * g + h) ^ ((row >> 1) & 7)) << 4));
-        const u32x2 s01 = __builtin_amdgcn_permlane32_swap(__float_as_uint(q[0]), __float_as_uint(q[1]), false, false);
-        const u32x2 s23 = __builtin_amdgcn_permlane32_swap(__float_as_uint(q[2]), __float_as_uint(q[3]), false, false);
-        af[i][0] = __uint_as_float(s01[0]);
-        af[i][2] = __uint_as_float(s01[1]);
-        af[i][1] = __uint_as_float(s23[0]);
-        af[i][3] = __uint_as_float(s23[1]);
+        af[i] = *reinterpret_cast<const f32x4*>(sA + row * 128 + (((2 * g + h) ^ ((row >> 1) & 7)) << 4));
       }
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         if (!DGRAD) {
           const int row = (wn * TN + j) * 32 + lrow;
-          const f32x4 q = *reinterpret_cast<const f32x4*>(sB + row * 128 + (((2 * g + h) ^ ((row >> 1) & 7)) << 4));
-          const u32x2 s01 = __builtin_amdgcn_permlane32_swap(__float_as_uint(q[0]), __float_as_uint(q[1]), false, false);
-          const u32x2 s23 = __builtin_amdgcn_permlane32_swap(__float_as_uint(q[2]), __float_as_uint(q[3]), false, false);
-          bf[j][0] = __uint_as_float(s01[0]);
-          bf[j][2] = __uint_as_float(s01[1]);
-          bf[j][1] = __uint_as_float(s23[0]);
-          bf[j][3] = __uint_as_float(s23[1]);
+          bf[j] = *reinterpret_cast<const f32x4*>(sB + row * 128 + (((2 * g + h) ^ ((row >> 1) & 7)) << 4));
         } else {
           const int col = (wn * TN + j) * 32 + lrow;
           const float* tb = reinterpret_cast<const float*>(sB);
 #pragma unroll
-          for (int st = 0; st < 4; ++st) bf[j][st] = tb[(g * 8 + 2 * st + h) * BN + col];
+          for (int st = 0; st < 4; ++st) bs[j][st] = tb[(g * 8 + 4 * h + st) * BN + col];
         }
       }
-      // af/bf[.][st] now hold MFMA step st of this group (k = 8g + 2st + h)
 #pragma unroll
       for (int st = 0; st < 4; ++st)
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
           for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][st], bf[j][st], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][st], DGRAD ? bs[j][st] : bf[j][st], acc[i][j], 0, 0, 0);
     }
   }
 
