@@ -42,6 +42,16 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 
+// One LDS-DMA instruction (global_load_lds_dwordx4: 64 lanes x 16 B -> 1 KiB at lds_base + lane*16), issued
+// as inline asm so that hipcc does not serialise it against the surrounding ds_reads (it would wait
+// vmcnt(0) before every LDS read that follows a DMA it knows about).  Ordering is by hand: every wave
+// executes `s_waitcnt vmcnt(0)` before the barrier that precedes the first read of the tile.
+__device__ __forceinline__ void lds_dma16(const float* gptr, unsigned lds_addr) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gptr), "s"(lds_addr) : "memory", "m0");
+#endif
+}
+
 template <int BM, int BN, int WM, int WN, bool DGRAD>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a, const int tiles_n) {
 #if defined(__HIP_DEVICE_COMPILE__)  // the host pass only needs the launch stub (amdgcn builtins below)
@@ -123,41 +133,50 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a, const
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
+  // LDS byte address of smem (a 32-bit LDS pointer), wave-uniform
+  const unsigned lds0 = (unsigned)(unsigned long long)LDS_PTR(smem);
   const int cchunks = a.Kc >> 5;
   const int T = a.ntaps * cchunks;
 
-  auto stage = [&](int t, int buf) {
+  // LDS-DMA of tile t into buffer buf; `part` selects a quarter of the instructions (or -1: all) so the
+  // issue cost (~100 cycles per instruction) can be spread behind the MFMA groups of the current tile
+  auto stage = [&](int t, int buf, int part) {
     const int tap = t / cchunks;
     const int cc = t - tap * cchunks;
-    const long long a_koff = (long long)((int)a.tap_dy[tap] * a.a_Wp + (int)a.tap_dx[tap]) * a.a_cs + cc * 32;
-    unsigned char* sA = smem + buf * STAGE;
-    unsigned char* sB = sA + A_BYTES;
+    // tap tables are bit-packed kernel arguments: pure scalar ALU, no memory access in the k-loop
+    const int tdy = (int)((a.pk_dy >> (2 * tap)) & 3u) - 1, tdx = (int)((a.pk_dx >> (2 * tap)) & 3u) - 1;
+    const int tw = (int)((a.pk_w >> (4 * tap)) & 15ull);
+    const long long a_koff = (long long)(tdy * a.a_Wp + tdx) * a.a_cs + cc * 32;
 #pragma unroll
     for (int j = 0; j < A_INSTR; ++j)
-      __builtin_amdgcn_global_load_lds(a_src[j] + a_koff, LDS_PTR(sA + (j * 4 + wave) * 1024), 16, 0, 0);
+      if (part < 0 || (j & 3) == part || (A_INSTR < 4 && part == j))
+        lds_dma16(a_src[j] + a_koff, lds0 + buf * STAGE + (j * 4 + wave) * 1024);
     if (!DGRAD) {
-      const int b_koff = (int)a.tap_w[tap] * a.w_cin + cc * 32;
+      const int b_koff = tw * a.w_cin + cc * 32;
 #pragma unroll
       for (int j = 0; j < B_INSTR; ++j)
-        __builtin_amdgcn_global_load_lds(b_src[j] + b_koff, LDS_PTR(sB + (j * 4 + wave) * 1024), 16, 0, 0);
+        if (part < 0 || (j & 3) == part || (B_INSTR < 4 && part == j))
+          lds_dma16(b_src[j] + b_koff, lds0 + buf * STAGE + A_BYTES + (j * 4 + wave) * 1024);
     } else {
 #pragma unroll
       for (int j = 0; j < B_INSTR; ++j) {
+        if (!(part < 0 || (j & 3) == part || (B_INSTR < 4 && part == j))) continue;
         int o = cc * 32 + b_krow[j];
         o = o < a.w_cout ? o : a.w_cout - 1;  // padded k rows: A is zero there
-        const long long off = ((long long)o * a.w_taps + (int)a.tap_w[tap]) * a.w_cin;
-        __builtin_amdgcn_global_load_lds(b_src[j] + off, LDS_PTR(sB + (j * 4 + wave) * 1024), 16, 0, 0);
+        const long long off = ((long long)o * a.w_taps + tw) * a.w_cin;
+        lds_dma16(b_src[j] + off, lds0 + buf * STAGE + A_BYTES + (j * 4 + wave) * 1024);
       }
     }
   };
 
-  stage(0, 0);
+  stage(0, 0, -1);
   const int lrow = lane & 31;
   for (int t = 0; t < T; ++t) {
     // tile t has landed (own DMA waited, then everyone's via the barrier) and every wave is done
     // reading the other buffer (it computed tile t-1 before arriving here)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of tile t has landed
     if (!(a.debug & 2)) __syncthreads();
-    if (t + 1 < T && !(a.debug & 1)) stage(t + 1, (t + 1) & 1);
+    const bool more = (t + 1 < T) && !(a.debug & 1);
     const unsigned char* sA = smem + (t & 1) * STAGE;
     const unsigned char* sB = sA + A_BYTES;
     // Per 8-k group g: the lower half-wave reads 16-B chunk 2g (channels 8g..8g+3), the upper half
@@ -187,12 +206,15 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a, const
         }
       }
 #pragma unroll
-      for (int st = 0; st < 4; ++st)
+      for (int st = 0; st < 4; ++st) {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
           for (int j = 0; j < TN; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][st], DGRAD ? bs[j][st] : bf[j][st], acc[i][j], 0, 0, 0);
+        // a quarter of the next tile's DMA, issued while this group's MFMAs occupy the matrix pipe
+        if (st == 0 && more) stage(t + 1, (t + 1) & 1, g);
+      }
     }
   }
 
@@ -327,6 +349,14 @@ hipError_t vy_launch_conv_igemm(const ConvArgs& a_in, hipStream_t s) {
   static const int dbg = getenv("VY_DEBUG_CONV") ? atoi(getenv("VY_DEBUG_CONV")) : 0;
   ConvArgs a = a_in;
   a.debug = dbg;
+  a.pk_dy = a.pk_dx = 0;
+  a.pk_w = 0;
+  for (int t = 0; t < a.ntaps; ++t) {
+    if (a.tap_dy[t] < -1 || a.tap_dy[t] > 1 || a.tap_dx[t] < -1 || a.tap_dx[t] > 1 || a.tap_w[t] > 15) return hipErrorInvalidValue;
+    a.pk_dy |= (unsigned)(a.tap_dy[t] + 1) << (2 * t);
+    a.pk_dx |= (unsigned)(a.tap_dx[t] + 1) << (2 * t);
+    a.pk_w |= (unsigned long long)a.tap_w[t] << (4 * t);
+  }
   if (a.Kc % 32 != 0 || a.ntaps < 1 || a.ntaps > 9 || a.M <= 0 || a.N <= 0) return hipErrorInvalidValue;
   if (a.dgrad && (a.N % 4 != 0)) return hipErrorInvalidValue;
   int bm, bn;

@@ -34,6 +34,8 @@ struct ConvArgs {
   int leaky;            // LeakyReLU(0.1) after the affine
   int dgrad;            // 0: W is the [n][k] operand (forward); 1: W is the [k][n] operand (dgrad)
   int debug;            // timing experiments (VY_DEBUG_CONV); 0 in production
+  unsigned pk_dy, pk_dx;        // filled by the launcher: tap tables packed 2 bits / tap (value + 1)
+  unsigned long long pk_w;      // 4 bits / tap
 };
 
 // 3x3/1x1 implicit-GEMM convolution on v_mfma_f32_32x32x2_f32.
