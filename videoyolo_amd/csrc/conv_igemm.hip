@@ -218,36 +218,47 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a, const
     }
   }
 
-  // epilogue: affine (folded BN or bias) -> leaky -> + addend -> store (x1 or x2-replicated)
+  // epilogue: affine (folded BN or bias) -> leaky -> + addend -> store (x1 or x2-replicated).
+  // Loads of the addend are unconditional (invalid rows / columns read a clamped, valid address) so
+  // that all 16*TM of a column tile are in flight together; only the stores are predicated.
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int n = n0 + (wn * TN + j) * 32 + lrow;
     const bool nvalid = n < a.N;
+    const int nc = nvalid ? n : a.N - 1;
     float sc = 1.0f, sh = 0.0f;
-    if (nvalid) {
-      if (a.scale) sc = a.scale[n];
-      if (a.shift) sh = a.shift[n];
-    }
+    if (a.scale) sc = a.scale[nc];
+    if (a.shift) sh = a.shift[nc];
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
+      long long op[16];
+      float rv[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        const long long op = o_pix[row];
-        if (op < 0 || !nvalid) continue;
+        op[r] = o_pix[row];
+      }
+      if (a.res) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) rv[r] = a.res[(op[r] < 0 ? 0 : op[r]) * a.r_cs + a.r_co + nc];
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
         float vv = acc[i][j][r];
         if (a.scale)
           vv = fmaf(vv, sc, sh);
         else if (a.shift)
           vv = vv + sh;
         if (a.leaky) vv = vy_leaky(vv);
-        if (a.res) vv = vv + a.res[op * a.r_cs + a.r_co + n];
-        float* o = a.out + op * a.o_cs + a.o_co + n;
-        o[0] = vv;
-        if (a.ups == 2) {
-          o[a.o_cs] = vv;
-          o[(long long)a.o_Wp * a.o_cs] = vv;
-          o[(long long)(a.o_Wp + 1) * a.o_cs] = vv;
+        if (a.res) vv = vv + rv[r];
+        if (op[r] >= 0 && nvalid) {
+          float* o = a.out + op[r] * a.o_cs + a.o_co + n;
+          o[0] = vv;
+          if (a.ups == 2) {
+            o[a.o_cs] = vv;
+            o[(long long)a.o_Wp * a.o_cs] = vv;
+            o[(long long)(a.o_Wp + 1) * a.o_cs] = vv;
+          }
         }
       }
     }

@@ -16,6 +16,10 @@ template <int COUT>
 __global__ __launch_bounds__(256) void stem_kernel(const StemArgs a) {
   __shared__ float sw[COUT * 27];
   __shared__ float ssc[COUT], ssh[COUT];
+  // output staging: thread t owns row t (its pixel's COUT channels); rows padded to 36 floats so the
+  // float4 row writes and the transposed float4 reads below stay 16-B aligned and spread over banks
+  __shared__ __attribute__((aligned(16))) float stage[256][COUT + 4];
+  __shared__ long long spix[256];
   for (int i = threadIdx.x; i < COUT * 27; i += 256) sw[i] = a.w[i];
   for (int i = threadIdx.x; i < COUT; i += 256) {
     ssc[i] = a.scale[i];
@@ -24,36 +28,50 @@ __global__ __launch_bounds__(256) void stem_kernel(const StemArgs a) {
   __syncthreads();
   const long long npix = (long long)a.B * a.H * a.W;
   const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (p >= npix) return;
-  const int x = (int)(p % a.W);
-  const long long t = p / a.W;
-  const int y = (int)(t % a.H);
-  const int b = (int)(t / a.H);
-  float in[27];
-  const float* xb = a.x + (long long)b * 3 * a.H * a.W;
+  if (p < npix) {
+    const int x = (int)(p % a.W);
+    const long long t = p / a.W;
+    const int y = (int)(t % a.H);
+    const int b = (int)(t / a.H);
+    float in[27];
+    const float* xb = a.x + (long long)b * 3 * a.H * a.W;
 #pragma unroll
-  for (int kh = 0; kh < 3; ++kh)
+    for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
-    for (int kw = 0; kw < 3; ++kw) {
-      const int iy = y + kh - 1, ix = x + kw - 1;
-      const bool ok = iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+      for (int kw = 0; kw < 3; ++kw) {
+        const int iy = y + kh - 1, ix = x + kw - 1;
+        const bool ok = iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
 #pragma unroll
-      for (int c = 0; c < 3; ++c)
-        in[(kh * 3 + kw) * 3 + c] = ok ? xb[((long long)c * a.H + iy) * a.W + ix] : 0.0f;
+        for (int c = 0; c < 3; ++c)
+          in[(kh * 3 + kw) * 3 + c] = ok ? xb[((long long)c * a.H + iy) * a.W + ix] : 0.0f;
+      }
+    spix[threadIdx.x] = ((long long)(b * (a.H + 2) + y + 1) * (a.W + 2) + x + 1) * a.out_cs + a.out_co;
+#pragma unroll
+    for (int o4 = 0; o4 < COUT; o4 += 4) {
+      f32x4 r;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float acc = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 27; ++k) acc = fmaf(in[k], sw[(o4 + q) * 27 + k], acc);
+        acc = fmaf(acc, ssc[o4 + q], ssh[o4 + q]);
+        r[q] = vy_leaky(acc);
+      }
+      *reinterpret_cast<f32x4*>(&stage[threadIdx.x][o4]) = r;
     }
-  float* o = a.out + ((long long)(b * (a.H + 2) + y + 1) * (a.W + 2) + x + 1) * a.out_cs + a.out_co;
+  } else {
+    spix[threadIdx.x] = -1;
+  }
+  __syncthreads();
+  // coalesced write-out: 8 consecutive lanes cover one pixel's 128-B channel vector, so every store
+  // instruction writes whole 128-B lines (a thread-per-pixel store would touch 64 lines, 16 B each)
+  constexpr int CH4 = COUT / 4;
 #pragma unroll
-  for (int o4 = 0; o4 < COUT; o4 += 4) {
-    f32x4 r;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      float acc = 0.0f;
-#pragma unroll
-      for (int k = 0; k < 27; ++k) acc = fmaf(in[k], sw[(o4 + q) * 27 + k], acc);
-      acc = fmaf(acc, ssc[o4 + q], ssh[o4 + q]);
-      r[q] = vy_leaky(acc);
-    }
-    *reinterpret_cast<f32x4*>(o + o4) = r;
+  for (int it = 0; it < CH4; ++it) {
+    const int lin = it * 256 + threadIdx.x;
+    const int pix = lin / CH4, c4 = (lin % CH4) * 4;
+    const long long o = spix[pix];
+    if (o >= 0) *reinterpret_cast<f32x4*>(a.out + o + c4) = *reinterpret_cast<const f32x4*>(&stage[pix][c4]);
   }
 }
 
