@@ -134,6 +134,14 @@ typedef struct vy_launch_stat {
 int vy_net_profile_infer(vy_net* net, const float* x, float* ids, float* scores, float* bboxes,
                          vy_launch_stat* stats, int32_t* n, void* stream);
 
+/* Frame pre-processing in front of the path: (batch,H,W,3) uint8 HWC device
+ * frames -> (batch,3,H,W) fp32 NCHW, y = (x/255 - mean[c]) / std[c] — mx.nd.image.to_tensor +
+ * mx.nd.image.normalize at models/definitions/yolo/transforms.py:331-334.  mean3/std3 are host
+ * pointers to 3 floats.  (The resize in front of it, transforms.py:325-327 imresize(interp=9), is
+ * OpenCV's area/bicubic and is not part of this library: frames arrive at the network size.) */
+int vy_preprocess_frames(const uint8_t* frames_hwc, float* out_nchw, int32_t batch, int32_t height,
+                         int32_t width, const float* mean3, const float* std3, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Training step.  Reference call pattern, train_yolov3.py:623-634:
  *     with autograd.record():

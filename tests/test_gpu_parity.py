@@ -135,3 +135,31 @@ def test_ties_and_empty():
     net = _net(classes, params)
     ids, scores, bboxes, keep = [t.cpu().numpy() for t in net(x, return_index=True)]
     assert (ids == -1).all() and (scores == -1).all() and (bboxes == -1).all() and (keep == -1).all()
+
+
+def test_preprocess_and_postprocess(voc_classes, synth20):
+    """to_tensor + normalize kernel is bit-equal to the numpy formula (transforms.py:331-334); the
+    post-processing helpers reproduce detect_yolo3.py:226,256-265,327-330."""
+    import torch
+    from videoyolo_amd import transforms
+    rng = np.random.default_rng(0)
+    frames_u8 = rng.integers(0, 256, (3, 96, 96, 3), dtype=np.uint8)
+    t = transforms.YOLO3VideoInferenceTransform(96, 96)
+    x = t(frames_u8)
+    want = ((frames_u8.astype(np.float32) / np.float32(255.0) - np.array(transforms.MEAN, np.float32))
+            / np.array(transforms.STD, np.float32)).transpose(0, 3, 1, 2)
+    assert x.shape == (3, 3, 96, 96)
+    assert np.array_equal(x.cpu().numpy(), want)
+    with pytest.raises(ValueError):
+        t(frames_u8[:, :64])
+    net = _net(voc_classes, synth20)
+    ids, scores, bboxes = net(x)
+    rows = transforms.postprocess(ids, scores, bboxes, 96)
+    assert len(rows) == 3
+    i_np, b_np = ids.cpu().numpy(), np.clip(bboxes.cpu().numpy(), 0, 96)
+    for i, r in enumerate(rows):
+        k = int((i_np[i] >= 0).sum())
+        assert r.shape == (k, 6) and (r[:, 2:] >= 0).all() and (r[:, 2:] <= 1).all()
+        np.testing.assert_allclose(r[:, 2:], b_np[i, :k] / 96.0)
+    line = transforms.prediction_lines("a/b.jpg", rows[0][:1])[0]
+    assert line.startswith("a/b.jpg,%d," % int(rows[0][0, 0])) and line.count(",") == 6
