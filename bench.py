@@ -46,6 +46,9 @@ def main():
                          "fwd + bwd + gradient all-reduce + SGD)")
     ap.add_argument("--syncbn", action="store_true", help="train: SyncBatchNorm statistics all-reduce (configs[4])")
     ap.add_argument("--no-overlap", action="store_true", help="train: all-reduce after backward instead of bucketed")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL over xGMI)")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="testing only: all ranks use cuda:0 (with --backend gloo) to exercise the N>1 code path on one GPU")
     args = ap.parse_args()
     if args.mode == "train":
         if "--size" not in " ".join(sys.argv):
@@ -68,8 +71,10 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local))
+        if args.share_gpu:
+            local = 0
+        kw = {"device_id": torch.device("cuda", local)} if args.backend == "nccl" else {}
+        dist.init_process_group(args.backend, rank=rank, world_size=world, **kw)
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
 
