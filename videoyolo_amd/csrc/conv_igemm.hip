@@ -24,7 +24,7 @@
 // order 0,4,1,5,2,6,3,7 per aligned group of 8 — the order the CPU checker uses too, which makes
 // the conv stack bit-reproducible with zero cross-lane traffic.
 //
-// Tiling (MI355X): 256 threads = 4 waves; block tile 128 x BN x 32(k); per k-step the A and W
+// Tiling (MI355X): 4 waves (128 x BN tiles) or 8 waves (256 x 128); k-step 32; per k-step the A and W
 // tiles (128 B per row) are brought in by LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave
 // instruction) into a double buffer; the 16-B chunk index is XOR-swizzled on the SOURCE side with
 // (row>>1)&7 so the ds_read_b128 of 32 different rows at one k-chunk is bank-conflict free.
@@ -53,12 +53,14 @@ __device__ __forceinline__ void lds_dma16(const float* gptr, unsigned lds_addr) 
 }
 
 template <int BM, int BN, int WM, int WN, bool DGRAD>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a, const int tiles_n) {
+__global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const ConvArgs a, const int tiles_n) {
 #if defined(__HIP_DEVICE_COMPILE__)  // the host pass only needs the launch stub (amdgcn builtins below)
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
   constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
-  constexpr int A_INSTR = BM / 32, B_INSTR = BN / 32;  // LDS-DMA instructions per wave per k-step
-  static_assert(WM * WN == 4, "4 waves");
+  constexpr int NW = WM * WN, NT = NW * 64;               // waves / threads per block
+  constexpr int A_INSTR = BM / 8 / NW, B_INSTR = BN / 8 / NW;  // LDS-DMA instructions per wave per k-step
+  static_assert(NW == 4 || NW == 8, "4 or 8 waves");
+  static_assert(A_INSTR >= 1 && B_INSTR >= 1, "tile too small for the wave count");
   static_assert(TM >= 1 && TN >= 1, "tile");
   // one LDS object: [stage0 A|W][stage1 A|W][row tables]
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE + 2 * BM * 8];
@@ -82,15 +84,15 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a, const
   const int tile_m = v / tiles_n, tile_n = v - tile_m * tiles_n;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
-  if (tid < BM) {
-    const int m = m0 + tid;
+  for (int rr = tid; rr < BM; rr += NT) {
+    const int m = m0 + rr;
     const int mm = m < a.M ? m : a.M - 1;
     const int x = mm % a.LW;
     const int t = mm / a.LW;
     const int y = t % a.LH;
     const int b = t / a.LH;
-    in_off[tid] = ((long long)(b * a.a_Hp + y * a.a_s + a.a_oy) * a.a_Wp + x * a.a_s + a.a_ox) * a.a_cs + a.a_co;
-    o_pix[tid] = (m < a.M) ? ((long long)(b * a.o_Hp + y * a.o_s + a.o_oy) * a.o_Wp + x * a.o_s + a.o_ox) : -1;
+    in_off[rr] = ((long long)(b * a.a_Hp + y * a.a_s + a.a_oy) * a.a_Wp + x * a.a_s + a.a_ox) * a.a_cs + a.a_co;
+    o_pix[rr] = (m < a.M) ? ((long long)(b * a.o_Hp + y * a.o_s + a.o_oy) * a.o_Wp + x * a.o_s + a.o_ox) : -1;
   }
   __syncthreads();
 
@@ -99,7 +101,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a, const
   const float* b_src[B_INSTR];
 #pragma unroll
   for (int j = 0; j < A_INSTR; ++j) {
-    const int row = (j * 4 + wave) * 8 + (lane >> 3);
+    const int row = (j * NW + wave) * 8 + (lane >> 3);
     const int chunk = (lane & 7) ^ ((row >> 1) & 7);
     a_src[j] = a.in + in_off[row] + chunk * 4;
   }
@@ -108,7 +110,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a, const
 #pragma unroll
   for (int j = 0; j < B_INSTR; ++j) {
     if (!DGRAD) {
-      const int row = (j * 4 + wave) * 8 + (lane >> 3);
+      const int row = (j * NW + wave) * 8 + (lane >> 3);
       const int chunk = (lane & 7) ^ ((row >> 1) & 7);
       int n = n0 + row;
       n = n < a.N ? n : a.N - 1;
@@ -117,7 +119,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a, const
     } else {
       constexpr int CPR = BN / 4;    // 16-B chunks per k-row
       constexpr int RPI = 64 / CPR;  // k-rows per wave instruction
-      const int row = (j * 4 + wave) * RPI + lane / CPR;
+      const int row = (j * NW + wave) * RPI + lane / CPR;
       int n = n0 + (lane % CPR) * 4;
       n = n < a.N ? n : 0;
       b_src[j] = a.w + n;
@@ -149,22 +151,22 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a, const
     const long long a_koff = (long long)(tdy * a.a_Wp + tdx) * a.a_cs + cc * 32;
 #pragma unroll
     for (int j = 0; j < A_INSTR; ++j)
-      if (part < 0 || (j & 3) == part || (A_INSTR < 4 && part == j))
-        lds_dma16(a_src[j] + a_koff, lds0 + buf * STAGE + (j * 4 + wave) * 1024);
+      if (part < 0 || (j & 3) == part)
+        lds_dma16((a.debug & 4) ? a.in + lane * 4 : a_src[j] + a_koff, lds0 + buf * STAGE + (j * NW + wave) * 1024);
     if (!DGRAD) {
       const int b_koff = tw * a.w_cin + cc * 32;
 #pragma unroll
       for (int j = 0; j < B_INSTR; ++j)
-        if (part < 0 || (j & 3) == part || (B_INSTR < 4 && part == j))
-          lds_dma16(b_src[j] + b_koff, lds0 + buf * STAGE + A_BYTES + (j * 4 + wave) * 1024);
+        if (part < 0 || (j & 3) == part)
+          lds_dma16((a.debug & 4) ? a.w + lane * 4 : b_src[j] + b_koff, lds0 + buf * STAGE + A_BYTES + (j * NW + wave) * 1024);
     } else {
 #pragma unroll
       for (int j = 0; j < B_INSTR; ++j) {
-        if (!(part < 0 || (j & 3) == part || (B_INSTR < 4 && part == j))) continue;
+        if (!(part < 0 || (j & 3) == part)) continue;
         int o = cc * 32 + b_krow[j];
         o = o < a.w_cout ? o : a.w_cout - 1;  // padded k rows: A is zero there
         const long long off = ((long long)o * a.w_taps + tw) * a.w_cin;
-        lds_dma16(b_src[j] + off, lds0 + buf * STAGE + A_BYTES + (j * 4 + wave) * 1024);
+        lds_dma16(b_src[j] + off, lds0 + buf * STAGE + A_BYTES + (j * NW + wave) * 1024);
       }
     }
   };
@@ -315,10 +317,10 @@ template <int BM, int BN, int WM, int WN>
 static hipError_t launch_cfg(const ConvArgs& a, hipStream_t s) {
   const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + BN - 1) / BN;
   if (a.dgrad)
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, true>), dim3(tiles_m * tiles_n), dim3(256), 0, s, a,
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, true>), dim3(tiles_m * tiles_n), dim3(WM * WN * 64), 0, s, a,
                        tiles_n);
   else
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, false>), dim3(tiles_m * tiles_n), dim3(256), 0, s, a,
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, false>), dim3(tiles_m * tiles_n), dim3(WM * WN * 64), 0, s, a,
                        tiles_n);
   return hipGetLastError();
 }
@@ -334,7 +336,13 @@ static void select_cfg(const ConvArgs& a, int* bm, int* bn) {
     return;
   }
   const long long want = 1024;
-  if (a.N > 64 && blocks(128, 128) >= want) {
+  // measured slower than 128x128 at 2 blocks/CU (110 vs 120 TF on the 76x76 layers: its two waves per
+  // SIMD share one barrier and run in lockstep); kept as an experiment switch
+  static const int big = getenv("VY_CONV_BIG") ? atoi(getenv("VY_CONV_BIG")) : 0;
+  if (big && a.N > 64 && blocks(256, 128) >= 2 * want) {
+    *bm = 256;  // 512 threads, one block per CU: 25 % fewer LDS-DMA instructions per FLOP
+    *bn = 128;
+  } else if (a.N > 64 && blocks(128, 128) >= want) {
     *bm = 128;
     *bn = 128;
   } else if (blocks(128, 64) >= want || a.M <= 64) {
@@ -375,5 +383,6 @@ hipError_t vy_launch_conv_igemm(const ConvArgs& a_in, hipStream_t s) {
   if (bn == 32) return launch_cfg<128, 32, 4, 1>(a, s);
   if (bm == 128 && bn == 64) return launch_cfg<128, 64, 2, 2>(a, s);
   if (bm == 64) return launch_cfg<64, 64, 2, 2>(a, s);
+  if (bm == 256) return launch_cfg<256, 128, 4, 2>(a, s);
   return launch_cfg<128, 128, 2, 2>(a, s);
 }
