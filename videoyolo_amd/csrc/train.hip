@@ -11,6 +11,8 @@
 //   overwrites z) -> wgrad (split-K slabs + ordered reduce) -> dgrad into the input's gradient plane
 //   (overwrite, or accumulate when the plane already holds another consumer's contribution, plus
 //   the skip connection's gradient as an addend).
+#include <cstdlib>
+
 #include "net_internal.h"
 
 namespace {
@@ -54,6 +56,14 @@ struct VyTrain {
   void* gb_user = nullptr;
   bool forward_done = false;
   int M = 0;
+  // weight gradients run on a side stream, concurrently with the dgrad / BatchNorm chain
+  hipStream_t side = nullptr;
+  hipEvent_t ev_main = nullptr, ev_side = nullptr;
+  ~VyTrain() {
+    if (ev_main) (void)hipEventDestroy(ev_main);
+    if (ev_side) (void)hipEventDestroy(ev_side);
+    if (side) (void)hipStreamDestroy(side);
+  }
 };
 
 void vy_train_free(vy_net* net) {
@@ -410,7 +420,7 @@ BwdDgrad make_dgrad(const TrainCtx& c, const ConvT& cv, const float* dzp, int dz
   return out;
 }
 
-int launch_wgrad(const TrainCtx& c, size_t ci, const float* dzp, int dz_cs, int Ho, int Wo) {
+int launch_wgrad(const TrainCtx& c, size_t ci, const float* dzp, int dz_cs, int Ho, int Wo, hipStream_t ws) {
   vy_net* net = c.net;
   const ConvT& cv = net->convs[ci];
   const PlaneT& ip = net->planes[cv.in_plane];
@@ -435,9 +445,9 @@ int launch_wgrad(const TrainCtx& c, size_t ci, const float* dzp, int dz_cs, int 
   w.Cin = cv.cin;
   w.splits = c.t->splits[ci];
   w.k_per_split = c.t->kps[ci];
-  HIP_TRY(vy_launch_wgrad(w, c.s));
+  HIP_TRY(vy_launch_wgrad(w, ws));
   HIP_TRY(vy_launch_slab_reduce(c.slabs(), w.splits, (long long)cv.cout * cv.k * cv.k * cv.cin,
-                                c.grad_of(cv.p_weight), c.s));
+                                c.grad_of(cv.p_weight), ws));
   return 0;
 }
 
@@ -466,8 +476,15 @@ int backward_train(const TrainCtx& c, const float* x) {
     if (cv.name.rfind("stages.0", 0) == 0) return 3;
     return 0;
   };
+  auto join_side = [&]() -> int {
+    if (!c.t->side) return 0;
+    HIP_TRY(hipEventRecord(c.t->ev_side, c.t->side));
+    HIP_TRY(hipStreamWaitEvent(c.s, c.t->ev_side, 0));
+    return 0;
+  };
   auto emit_bucket = [&](int bk) -> int {
     if (!c.t->gb_cb) return 0;
+    if (int rc = join_side()) return rc;  // the bucket's weight gradients must be final
     int64_t lo = INT64_MAX, hi = 0;
     for (const ConvT& cv : net->convs) {
       if (bucket_of(cv) != bk) continue;
@@ -569,7 +586,14 @@ int backward_train(const TrainCtx& c, const float* x) {
       HIP_TRY(vy_launch_f64_to_f32(c.sums_local(), c.grad_of(cv.p_weight), 864, c.s));
       continue;  // no gradient w.r.t. the image
     }
-    if (int rc = launch_wgrad(c, (size_t)ci, dzp, dz_cs, dzH, dzW)) return rc;
+    // dz is final on the main stream: the weight gradient (its own scratch: the slabs) goes to the side
+    // stream and overlaps with this layer's dgrad and the next layers' BatchNorm kernels
+    hipStream_t ws = c.t->side ? c.t->side : c.s;
+    if (c.t->side) {
+      HIP_TRY(hipEventRecord(c.t->ev_main, c.s));
+      HIP_TRY(hipStreamWaitEvent(c.t->side, c.t->ev_main, 0));
+    }
+    if (int rc = launch_wgrad(c, (size_t)ci, dzp, dz_cs, dzH, dzW, ws)) return rc;
     // data gradient into the input view
     const int lo = cv.in_co, hi = cv.in_co + cv.cin;
     const int cov = covered(cv.in_plane, lo, hi);
@@ -595,6 +619,7 @@ int backward_train(const TrainCtx& c, const float* x) {
     if (cov == 0) touched[cv.in_plane].push_back({lo, hi});
   }
   if (int rc = emit_bucket(cur_bucket)) return rc;
+  if (int rc = join_side()) return rc;
   if (!skips.empty()) return fail(VY_ERR_STATE, "internal: unresolved skip gradient");
   return 0;
 }
@@ -625,6 +650,12 @@ int vy_net_bind_train(vy_net* net, void* dev_ws, size_t bytes, int32_t batch, in
   t->forward_done = false;
   hipStream_t s = static_cast<hipStream_t>(stream);
   HIP_TRY(hipMemsetAsync(dev_ws, 0, need, s));
+  static const int use_side = getenv("VY_TRAIN_SIDE_STREAM") ? atoi(getenv("VY_TRAIN_SIDE_STREAM")) : 1;
+  if (use_side && !t->side) {
+    HIP_TRY(hipStreamCreateWithFlags(&t->side, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&t->ev_main, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&t->ev_side, hipEventDisableTiming));
+  }
   return 0;
 }
 
