@@ -18,6 +18,14 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 
+// LDS-DMA as inline asm (see conv_igemm.hip: keeps hipcc from serialising it against the ds_reads);
+// ordered by hand: s_waitcnt vmcnt(0) before the barrier that precedes the first read of the tile.
+__device__ __forceinline__ void lds_dma16(const float* gptr, unsigned lds_addr) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gptr), "s"(lds_addr) : "memory", "m0");
+#endif
+}
+
 __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a, const int tiles_n) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int BM = 128, BN = 128, TILE = 32 * 128 * 4, STAGE = 2 * TILE;
@@ -56,49 +64,75 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a, const int
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-  auto stage = [&](int t, int buf) {
-    unsigned char* sA = smem + buf * STAGE;
-    unsigned char* sB = sA + TILE;
+  // Each lane stages the same 4 pixel rows of both tiles every k-step (row = 2*(j*4+wave) + h); their
+  // (b, oy, ox) are carried incrementally (+32 pixels per k-step) instead of being re-derived by
+  // integer division each time.
+  int pb[4], py[4], px[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int q = j * 4 + wave;
-      const int p = p_begin + t * 32 + 2 * q + h;
-      const float* pa = a.zero;
-      const float* pb = a.zero;
-      if (p < p_end) {
-        const int ox = p % a.Wo;
-        const int tt = p / a.Wo;
-        const int oy = tt % a.Ho;
-        const int b = tt / a.Ho;
-        if (a_ok) pa = a.dz + ((long long)(b * Hzp + oy + 1) * Wzp + ox + 1) * a.z_cs + ao;
-        if (b_ok)
-          pb = a.a + ((long long)(b * a.a_Hp + oy * a.stride + 1 + dy) * a.a_Wp + ox * a.stride + 1 + dx) * a.a_cs +
-               a.a_co + cin;
+  for (int j = 0; j < 4; ++j) {
+    const int p = p_begin + 2 * (j * 4 + wave) + h;
+    px[j] = p % a.Wo;
+    const int tt = p / a.Wo;
+    py[j] = tt % a.Ho;
+    pb[j] = tt / a.Ho;
+  }
+  const unsigned lds0 = (unsigned)(unsigned long long)LDS_PTR(smem);
+  // one quarter (instruction j) of the LDS-DMA of tile t into buffer buf
+  auto stage = [&](int t, int buf, int j) {
+    const int q = j * 4 + wave;
+    const int p = p_begin + t * 32 + 2 * q + h;
+    const float* pa = a.zero;
+    const float* pb_ = a.zero;
+    if (p < p_end) {
+      if (a_ok) pa = a.dz + ((long long)(pb[j] * Hzp + py[j] + 1) * Wzp + px[j] + 1) * a.z_cs + ao;
+      if (b_ok)
+        pb_ = a.a + ((long long)(pb[j] * a.a_Hp + py[j] * a.stride + 1 + dy) * a.a_Wp + px[j] * a.stride + 1 + dx) * a.a_cs +
+              a.a_co + cin;
+    }
+    lds_dma16(pa, lds0 + buf * STAGE + q * 1024);
+    lds_dma16(pb_, lds0 + buf * STAGE + TILE + q * 1024);
+    // advance this row by 32 pixels for the next tile
+    px[j] += 32;
+    while (px[j] >= a.Wo) {
+      px[j] -= a.Wo;
+      if (++py[j] == a.Ho) {
+        py[j] = 0;
+        ++pb[j];
       }
-      __builtin_amdgcn_global_load_lds(pa, LDS_PTR(sA + q * 1024), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds(pb, LDS_PTR(sB + q * 1024), 16, 0, 0);
     }
   };
 
-  if (T > 0) stage(0, 0);
+  if (T > 0) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) stage(0, 0, j);
+  }
   for (int t = 0; t < T; ++t) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of tile t has landed
     __syncthreads();
-    if (t + 1 < T) stage(t + 1, (t + 1) & 1);
+    const bool more = t + 1 < T;
     const float* tA = reinterpret_cast<const float*>(smem + (t & 1) * STAGE);
     const float* tB = tA + 32 * 128;
 #pragma unroll
-    for (int s = 0; s < 16; ++s) {
-      const int krow = (2 * s + h) * 128;
-      float av[2], bv[2];
+    for (int g = 0; g < 4; ++g) {
+      float av[4][2], bv[4][2];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) av[i] = tA[krow + (wm * 2 + i) * 32 + lrow];
+      for (int s4 = 0; s4 < 4; ++s4) {
+        const int krow = (2 * (g * 4 + s4) + h) * 128;
 #pragma unroll
-      for (int j = 0; j < 2; ++j) bv[j] = tB[krow + (wn * 2 + j) * 32 + lrow];
+        for (int i = 0; i < 2; ++i) av[s4][i] = tA[krow + (wm * 2 + i) * 32 + lrow];
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 2; ++j) bv[s4][j] = tB[krow + (wn * 2 + j) * 32 + lrow];
+      }
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+      for (int s4 = 0; s4 < 4; ++s4) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s4][i], bv[s4][j], acc[i][j], 0, 0, 0);
+        // a quarter of the next tile's DMA, issued while this group's MFMAs occupy the matrix pipe
+        if (s4 == 0 && more) stage(t + 1, (t + 1) & 1, g);
+      }
     }
   }
 
