@@ -82,8 +82,7 @@ def main():
     net = vy.yolo3_darknet53(classes, pretrained_base=False)
     net.initialize(init="synthetic", seed=233, obj_bias=args.obj_bias)
     net.collect_params().reset_ctx(dev)
-    net.set_nms(0.45, 400, 100)
-    net.hybridize()
+    net.set_nms(0.45, 400, 100)  # detect_yolo3.py:200; like the reference's detect() the net is not hybridized
 
     g = torch.Generator(device="cpu").manual_seed(233 + rank)
     x = torch.randn((args.batch, 3, args.size, args.size), generator=g, dtype=torch.float32).to(dev)

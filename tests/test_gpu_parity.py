@@ -163,3 +163,26 @@ def test_preprocess_and_postprocess(voc_classes, synth20):
         np.testing.assert_allclose(r[:, 2:], b_np[i, :k] / 96.0)
     line = transforms.prediction_lines("a/b.jpg", rows[0][:1])[0]
     assert line.startswith("a/b.jpg,%d," % int(rows[0][0, 0])) and line.count(",") == 6
+
+
+def test_hybridize_replays_a_hip_graph(voc_classes, synth20):
+    """net.hybridize(): the forward is captured once per shape and replayed; results are identical to
+    the eager path, set_nms() and a new input shape invalidate the capture (yolo3.py:1225)."""
+    import torch
+    x1, x2 = frames(2, 96, seed=1), frames(2, 96, seed=2)
+    net = _net(voc_classes, synth20)
+    eager1 = [t.clone() for t in net(x1, return_index=True)]
+    eager2 = [t.clone() for t in net(x2, return_index=True)]
+    net.hybridize()
+    for _ in range(2):
+        g1 = net(x1, return_index=True)
+        g2 = net(x2, return_index=True)
+        assert all(torch.equal(a, b) for a, b in zip(eager1, g1))
+        assert all(torch.equal(a, b) for a, b in zip(eager2, g2))
+    assert len(net._graphs) == 1
+    net.set_nms(0.3, 50, 20)
+    ids, _, _ = net(x1)
+    assert ids.shape == (2, 20, 1)
+    x3 = frames(1, 64, seed=3)
+    ids, _, _ = net(x3)
+    assert ids.shape == (1, 20, 1) and len(net._graphs) == 1

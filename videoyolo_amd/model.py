@@ -18,6 +18,7 @@ Call sites this surface serves (paths relative to /root/reference):
 """
 import copy
 import ctypes
+import os
 import re
 import warnings
 from collections import OrderedDict
@@ -134,6 +135,8 @@ class YOLOV3(object):
         self._cb_keep = []       # ctypes callbacks kept alive
         self._device = None
         self._hybrid = False
+        self._graphs = {}
+        self._use_graphs = os.environ.get("VY_HIP_GRAPHS", "1") != "0"
         _lib.check(self._lib.vy_net_set_nms(self._h, nms_thresh, nms_topk, post_nms))
 
     def __del__(self):
@@ -269,7 +272,42 @@ class YOLOV3(object):
 
     # ------------------------------------------------------------------ configuration
     def hybridize(self, active=True, **kwargs):
+        """``net.hybridize()`` (train_yolov3.py:441,586).  For inference the launch sequence of one
+        forward (85 kernels + 2 memsets) is captured into a HIP graph per input shape and replayed:
+        small batches are launch-bound, a replay costs one submission."""
         self._hybrid = bool(active)
+        self._graphs = {}
+
+    def _graph_forward(self, x, rows):
+        """Capture-once / replay path of detect() when hybridized."""
+        torch = _torch()
+        key = (tuple(x.shape), rows, self.nms_thresh, self.nms_topk, self.post_nms)
+        g = self._graphs.get(key)
+        if g is None:
+            b = x.shape[0]
+            st = dict(x=torch.empty_like(x),
+                      ids=torch.empty((b, rows, 1), dtype=torch.float32, device=self._device),
+                      scores=torch.empty((b, rows, 1), dtype=torch.float32, device=self._device),
+                      bboxes=torch.empty((b, rows, 4), dtype=torch.float32, device=self._device),
+                      keep=torch.empty((b, rows), dtype=torch.int32, device=self._device))
+
+            def launch():
+                _lib.check(self._lib.vy_net_forward_infer(
+                    self._h, ctypes.c_void_p(st["x"].data_ptr()), ctypes.c_void_p(st["ids"].data_ptr()),
+                    ctypes.c_void_p(st["scores"].data_ptr()), ctypes.c_void_p(st["bboxes"].data_ptr()),
+                    ctypes.c_void_p(st["keep"].data_ptr()), self._stream()))
+            st["x"].copy_(x)
+            launch()  # eager warm-up: one-time uploads happen outside the capture
+            torch.cuda.synchronize(self._device)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                launch()
+            g = (graph, st)
+            self._graphs = {key: g}  # one shape at a time (the workspace is planned for one shape)
+        graph, st = g
+        st["x"].copy_(x)
+        graph.replay()
+        return st["ids"].clone(), st["scores"].clone(), st["bboxes"].clone(), st["keep"].clone()
 
     def set_nms(self, nms_thresh=0.45, nms_topk=400, post_nms=100):
         """yolo3.py:1208-1228"""
@@ -383,6 +421,7 @@ class YOLOV3(object):
             _lib.check(self._lib.vy_net_bind_workspace(self._h, ctypes.c_void_p(self._ws.data_ptr()),
                                                        self._ws.numel(), b, h, w, self._stream()))
         self._plan = (b, h, w, bool(train))
+        self._graphs = {}
 
     def _as_input(self, x):
         torch = _torch()
@@ -505,8 +544,14 @@ class YOLOV3(object):
         x = self._as_input(x)
         b, _, h, w = x.shape
         with torch.cuda.device(self._device):
+            replanned = self._plan is None or self._plan[:3] != (b, h, w)
             self._ensure_plan(b, h, w)
             rows = self.post_nms if self.post_nms > 0 else self.nms_topk
+            if getattr(self, "_hybrid", False) and self._use_graphs:
+                if replanned:
+                    self._graphs = {}
+                ids, scores, bboxes, keep = self._graph_forward(x, rows)
+                return (ids, scores, bboxes, keep) if return_index else (ids, scores, bboxes)
             ids = torch.empty((b, rows, 1), dtype=torch.float32, device=self._device)
             scores = torch.empty((b, rows, 1), dtype=torch.float32, device=self._device)
             bboxes = torch.empty((b, rows, 4), dtype=torch.float32, device=self._device)
