@@ -152,13 +152,13 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const ConvArgs
 #pragma unroll
     for (int j = 0; j < A_INSTR; ++j)
       if (part < 0 || (j & 3) == part)
-        lds_dma16((a.debug & 4) ? a.in + lane * 4 : a_src[j] + a_koff, lds0 + buf * STAGE + (j * NW + wave) * 1024);
+        lds_dma16(a_src[j] + a_koff, lds0 + buf * STAGE + (j * NW + wave) * 1024);
     if (!DGRAD) {
       const int b_koff = tw * a.w_cin + cc * 32;
 #pragma unroll
       for (int j = 0; j < B_INSTR; ++j)
         if (part < 0 || (j & 3) == part)
-          lds_dma16((a.debug & 4) ? a.w + lane * 4 : b_src[j] + b_koff, lds0 + buf * STAGE + A_BYTES + (j * NW + wave) * 1024);
+          lds_dma16(b_src[j] + b_koff, lds0 + buf * STAGE + A_BYTES + (j * NW + wave) * 1024);
     } else {
 #pragma unroll
       for (int j = 0; j < B_INSTR; ++j) {
