@@ -186,3 +186,18 @@ def test_hybridize_replays_a_hip_graph(voc_classes, synth20):
     x3 = frames(1, 64, seed=3)
     ids, _, _ = net(x3)
     assert ids.shape == (1, 20, 1) and len(net._graphs) == 1
+
+
+def test_non_square_input(voc_classes, synth20):
+    """H != W (multiples of 32): planner, concat planes and decode offsets are per-axis."""
+    rng = np.random.default_rng(11)
+    x = rng.standard_normal((2, 3, 96, 160)).astype(np.float32)
+    net = _net(voc_classes, synth20)
+    ids, scores, bboxes, keep = [t.cpu().numpy() for t in net(x, return_index=True)]
+    r = _oracle(synth20)(x)
+    assert np.array_equal(keep, r[3]) and np.array_equal(ids, r[0])
+    np.testing.assert_allclose(scores, r[1], rtol=0, atol=TOL)
+    fin = np.isfinite(r[2])
+    np.testing.assert_allclose(bboxes[fin], r[2][fin], rtol=0, atol=TOL)
+    for i in range(3):
+        assert np.array_equal(net.read_head(i).cpu().numpy(), _oracle(synth20).raw_heads(x)[i])
