@@ -155,6 +155,20 @@ def main():
             "whole_step_tflops": total_fl / (total_ms * 1e-3) / 1e12,
             "by_kernel_ms": {k: round(a[1], 4) for k, a in agg.items()},
         }
+        result["roofline"]["algorithmic_bytes_per_launch_avg"] = by / n
+        # HBM bytes per launch of the same kernel from the committed rocprofv3 PMC passes of this command
+        # (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE; profiles/rNN_infer608_b64_pmc_hbm.json)
+        if (args.size, args.batch, args.classes) == (608, 64, 20):
+            import glob
+            pm = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_infer608_b64_pmc_hbm.json")))
+            if pm:
+                try:
+                    k = json.load(open(pm[-1]))["kernels"].get("void conv_igemm_kernel<128, 128, 2, 2, false>")
+                    if k:
+                        result["roofline"]["traffic"] = k["hbm_MB_per_launch"] * 1e6
+                        result["roofline"]["traffic_source"] = os.path.basename(pm[-1])
+                except Exception:
+                    pass
         tail = agg.get("decode_nms")
         if tail:
             result["roofline"]["decode_nms"] = {
