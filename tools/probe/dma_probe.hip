@@ -14,7 +14,7 @@ __device__ __forceinline__ void lds_dma16(const float* gptr, unsigned lds_addr) 
 
 // MODE 0: no DMA.  1: every compute wave issues 8 DMA per k-step (2 per MFMA group).  2: a fifth wave issues all 32.
 template <int MODE>
-__global__ __launch_bounds__(MODE == 2 ? 320 : 256) void probe(const float* src, float* out, int ksteps) {
+__global__ __launch_bounds__(MODE == 2 ? 320 : 256) void probe(const float* src, float* out, int ksteps, long long stream_mask) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[65536];
   const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, lrow = lane & 31;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -52,8 +52,10 @@ __global__ __launch_bounds__(MODE == 2 ? 320 : 256) void probe(const float* src,
         acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(q[1][s], q[3][s], acc[3], 0, 0, 0);
         if (MODE == 1 && s == 0) {
           const unsigned base = lds0 + ((t + 1) & 1) * 32768 + (g * 8 + wave * 2) * 1024;
-          lds_dma16(gp + g * 512, base);
-          lds_dma16(gp + g * 512 + 256, base + 1024);
+          // stream_mask != 0: every k-step reads a fresh 32 KiB of a large buffer (real L2/HBM traffic)
+          const long long so = (((long long)blockIdx.x * 977 + t) * 8192LL + (g * 8 + wave * 2) * 256) & stream_mask;
+          lds_dma16(gp + so, base);
+          lds_dma16(gp + so + 256, base + 1024);
         }
       }
     }
@@ -66,18 +68,20 @@ __global__ __launch_bounds__(MODE == 2 ? 320 : 256) void probe(const float* src,
 }
 
 template <int MODE>
-void run(const char* name, int blocks, int ksteps) {
+void run(const char* name, int blocks, int ksteps, long long stream_floats = 0) {
   float *out, *src;
   hipMalloc(&out, (size_t)blocks * 320 * 4);
-  hipMalloc(&src, (size_t)blocks * 64 * 16 + 65536 * 4);
-  hipMemset(src, 0, (size_t)blocks * 64 * 16 + 65536 * 4);
+  const size_t src_bytes = (size_t)blocks * 64 * 16 + 65536 * 4 + (size_t)stream_floats * 4;
+  hipMalloc(&src, src_bytes);
+  hipMemset(src, 0, src_bytes);
+  const long long mask = stream_floats ? stream_floats - 1 : 0;
   const int threads = MODE == 2 ? 320 : 256;
   hipEvent_t e0, e1;
   hipEventCreate(&e0); hipEventCreate(&e1);
-  hipLaunchKernelGGL(probe<MODE>, dim3(blocks), dim3(threads), 0, 0, src, out, ksteps);
+  hipLaunchKernelGGL(probe<MODE>, dim3(blocks), dim3(threads), 0, 0, src, out, ksteps, mask);
   hipDeviceSynchronize();
   hipEventRecord(e0);
-  hipLaunchKernelGGL(probe<MODE>, dim3(blocks), dim3(threads), 0, 0, src, out, ksteps);
+  hipLaunchKernelGGL(probe<MODE>, dim3(blocks), dim3(threads), 0, 0, src, out, ksteps, mask);
   hipEventRecord(e1);
   hipDeviceSynchronize();
   float ms; hipEventElapsedTime(&ms, e0, e1);
@@ -94,5 +98,7 @@ int main() {
   run<0>("no DMA, 3 rounds", 1536, ks / 2);
   run<1>("DMA by compute waves, 3 rounds", 1536, ks / 2);
   run<2>("DMA by loader wave, 3 rounds", 1536, ks / 2);
+  run<1>("DMA by compute waves, streaming 64 MiB (MALL)", 512, ks, 1LL << 24);
+  run<1>("DMA by compute waves, streaming 2 GiB (HBM)", 512, ks, 1LL << 29);
   return 0;
 }

@@ -32,6 +32,7 @@
 // dgrad reads W as the [k][n] operand: its LDS tile is 32 k-rows of BN contiguous floats, read with
 // ds_read_b32 (32 consecutive floats per half-wave: conflict-free without a swizzle).
 #include <cstdlib>
+#include <type_traits>
 
 #include "kernels.h"
 #include "../../include/vy_math.h"
@@ -52,8 +53,11 @@ __device__ __forceinline__ void lds_dma16(const float* gptr, unsigned lds_addr) 
 #endif
 }
 
-template <int BM, int BN, int WM, int WN, bool DGRAD>
-__global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const ConvArgs a, const int tiles_n) {
+template <int BM, int BN, int WM, int WN, bool DGRAD, int SCHED = 0>
+// 2nd launch-bounds argument = waves per SIMD the register allocation must allow: two (2 blocks/CU of 4
+// waves, or one 8-wave block).  Without it hipcc let the register count drift past 256 and silently
+// halved the occupancy of some variants.
+__global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_kernel(const ConvArgs a, const int tiles_n) {
 #if defined(__HIP_DEVICE_COMPILE__)  // the host pass only needs the launch stub (amdgcn builtins below)
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
   constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
@@ -171,8 +175,9 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const ConvArgs
     }
   };
 
-  stage(0, 0, -1);
   const int lrow = lane & 31;
+  if constexpr (SCHED == 0) {
+  stage(0, 0, -1);
   for (int t = 0; t < T; ++t) {
     // tile t has landed (own DMA waited, then everyone's via the barrier) and every wave is done
     // reading the other buffer (it computed tile t-1 before arriving here)
@@ -218,6 +223,114 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const ConvArgs
         if (st == 0 && more) stage(t + 1, (t + 1) & 1, g);
       }
     }
+  }
+
+  } else {
+    // ---- experimental schedules (VY_CONV_SCHED): wave-uniform tile state advanced once per tile with
+    // scalar adds, peeled last tile, explicit placement of the DMA quarter and of the next group's reads
+    int n_tap = 0, n_cc = 0;
+    long long a_koff = 0, b_koff = 0;
+    bool n_lastcc = false;
+    auto advance = [&]() {
+      const int tdy = (int)((a.pk_dy >> (2 * n_tap)) & 3u) - 1, tdx = (int)((a.pk_dx >> (2 * n_tap)) & 3u) - 1;
+      const int tw = (int)((a.pk_w >> (4 * n_tap)) & 15ull);
+      a_koff = (long long)(tdy * a.a_Wp + tdx) * a.a_cs + n_cc * 32;
+      if (!DGRAD)
+        b_koff = tw * a.w_cin + n_cc * 32;
+      else
+        b_koff = ((long long)n_cc * 32 * a.w_taps + tw) * a.w_cin;
+      n_lastcc = (n_cc == cchunks - 1);
+      if (++n_cc == cchunks) {
+        n_cc = 0;
+        ++n_tap;
+      }
+    };
+    long long b_row[B_INSTR], b_row_last[B_INSTR];
+#pragma unroll
+    for (int j = 0; j < B_INSTR; ++j) {
+      b_row[j] = (long long)b_krow[j] * a.w_taps * a.w_cin;
+      int o = (cchunks - 1) * 32 + b_krow[j];
+      o = o < a.w_cout ? o : a.w_cout - 1;
+      b_row_last[j] = (long long)(o - (cchunks - 1) * 32) * a.w_taps * a.w_cin;
+    }
+    // DMA instruction idx (A: 0..A_INSTR-1, W: A_INSTR..) goes behind MFMA group idx*3/total: groups 0-2
+    // carry everything, group 3 nothing, so the last DMA has a whole group (>= 16 MFMAs) to land before
+    // the tile-end vmcnt(0)
+    constexpr int DMA_TOTAL = A_INSTR + B_INSTR;
+    constexpr int DMA_GROUPS = (SCHED == 4) ? 2 : 3;
+    auto stage2 = [&](int buf, int part) {
+#pragma unroll
+      for (int j = 0; j < A_INSTR; ++j)
+        if (part < 0 || (j * DMA_GROUPS) / DMA_TOTAL == part) lds_dma16(a_src[j] + a_koff, lds0 + buf * STAGE + (j * NW + wave) * 1024);
+#pragma unroll
+      for (int j = 0; j < B_INSTR; ++j) {
+        if (!(part < 0 || ((A_INSTR + j) * DMA_GROUPS) / DMA_TOTAL == part)) continue;
+        const float* src = DGRAD ? b_src[j] + b_koff + (n_lastcc ? b_row_last[j] : b_row[j]) : b_src[j] + b_koff;
+        lds_dma16(src, lds0 + buf * STAGE + A_BYTES + (j * NW + wave) * 1024);
+      }
+    };
+    auto ktile = [&](int t, auto prefetch) {
+      constexpr bool PREFETCH = decltype(prefetch)::value;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (PREFETCH) advance();
+      const int nbuf = (t + 1) & 1;
+      const unsigned char* sA = smem + (t & 1) * STAGE;
+      const unsigned char* sB = sA + A_BYTES;
+      f32x4 af[2][TM], bf[2][TN];
+      float bs[2][TN][4];
+      auto load_group = [&](int g, int buf) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const int row = (wm * TM + i) * 32 + lrow;
+          af[buf][i] = *reinterpret_cast<const f32x4*>(sA + row * 128 + (((2 * g + h) ^ ((row >> 1) & 7)) << 4));
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          if (!DGRAD) {
+            const int row = (wn * TN + j) * 32 + lrow;
+            bf[buf][j] = *reinterpret_cast<const f32x4*>(sB + row * 128 + (((2 * g + h) ^ ((row >> 1) & 7)) << 4));
+          } else {
+            const int col = (wn * TN + j) * 32 + lrow;
+            const float* tb = reinterpret_cast<const float*>(sB);
+#pragma unroll
+            for (int st = 0; st < 4; ++st) bs[buf][j][st] = tb[(g * 8 + 4 * h + st) * BN + col];
+          }
+        }
+      };
+      auto mfma_step = [&](int buf, int st) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[buf][i][st], DGRAD ? bs[buf][j][st] : bf[buf][j][st],
+                                                             acc[i][j], 0, 0, 0);
+      };
+      load_group(0, 0);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int cur = g & 1;
+        // SCHED 1: [step0] DMA [step1 step2] reads(g+1) [step3]
+        // SCHED 2: [step0] DMA [step1] reads(g+1) [step2 step3]
+        // SCHED 3: [step0 step1] DMA [step2] reads(g+1) [step3]
+        mfma_step(cur, 0);
+        if (SCHED >= 3) mfma_step(cur, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (PREFETCH) stage2(nbuf, g);
+        __builtin_amdgcn_sched_barrier(0);
+        if (SCHED < 3) mfma_step(cur, 1);
+        if (SCHED != 2) mfma_step(cur, 2);
+        __builtin_amdgcn_sched_barrier(0);
+        if (g + 1 < 4) load_group(g + 1, cur ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (SCHED == 2) mfma_step(cur, 2);
+        mfma_step(cur, 3);
+      }
+    };
+    advance();
+    stage2(0, -1);
+    for (int t = 0; t + 1 < T; ++t) ktile(t, std::true_type{});
+    ktile(T - 1, std::false_type{});
   }
 
   // epilogue: affine (folded BN or bias) -> leaky -> + addend -> store (x1 or x2-replicated).
@@ -313,16 +426,26 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const ConvArgs
 #endif  // __HIP_DEVICE_COMPILE__
 }
 
-template <int BM, int BN, int WM, int WN>
-static hipError_t launch_cfg(const ConvArgs& a, hipStream_t s) {
+template <int BM, int BN, int WM, int WN, int SCHED>
+static hipError_t launch_sched(const ConvArgs& a, hipStream_t s) {
   const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + BN - 1) / BN;
   if (a.dgrad)
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, true>), dim3(tiles_m * tiles_n), dim3(WM * WN * 64), 0, s, a,
-                       tiles_n);
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, true, SCHED>), dim3(tiles_m * tiles_n), dim3(WM * WN * 64), 0,
+                       s, a, tiles_n);
   else
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, false>), dim3(tiles_m * tiles_n), dim3(WM * WN * 64), 0, s, a,
-                       tiles_n);
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, false, SCHED>), dim3(tiles_m * tiles_n), dim3(WM * WN * 64), 0,
+                       s, a, tiles_n);
   return hipGetLastError();
+}
+
+// k-loop schedule: 3 = [MFMA steps 0,1] DMA third [step 2] next group's ds_reads [step 3], the measured
+// best (VY_CONV_SCHED selects the others for experiments: 0 = scheduler's choice, 4 = DMA in two halves)
+template <int BM, int BN, int WM, int WN>
+static hipError_t launch_cfg(const ConvArgs& a, hipStream_t s) {
+  static const int sched = getenv("VY_CONV_SCHED") ? atoi(getenv("VY_CONV_SCHED")) : 3;
+  if (sched == 0) return launch_sched<BM, BN, WM, WN, 0>(a, s);
+  if (sched == 4) return launch_sched<BM, BN, WM, WN, 4>(a, s);
+  return launch_sched<BM, BN, WM, WN, 3>(a, s);
 }
 
 // Tile choice: the 128x128 tile has the best arithmetic intensity, but a launch needs >= ~2 blocks

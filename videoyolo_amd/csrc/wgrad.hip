@@ -26,7 +26,7 @@ __device__ __forceinline__ void lds_dma16(const float* gptr, unsigned lds_addr) 
 #endif
 }
 
-__global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a, const int tiles_n) {
+__global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a, const int tiles_n) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int BM = 128, BN = 128, TILE = 32 * 128 * 4, STAGE = 2 * TILE;
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
