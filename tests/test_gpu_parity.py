@@ -201,3 +201,24 @@ def test_non_square_input(voc_classes, synth20):
     np.testing.assert_allclose(bboxes[fin], r[2][fin], rtol=0, atol=TOL)
     for i in range(3):
         assert np.array_equal(net.read_head(i).cpu().numpy(), _oracle(synth20).raw_heads(x)[i])
+
+
+def test_two_stream_batch_split_is_identical(voc_classes, synth20):
+    """Large batches run as two half-batches on two HIP streams (twin handle sharing the parameters):
+    same results as the single-stream path, also after the parameters or NMS settings change."""
+    import torch
+    x = frames(6, 96, seed=4)
+    net = _net(voc_classes, synth20)
+    net.two_stream_batch = 0
+    one = [t.clone() for t in net(x, return_index=True)]
+    net.two_stream_batch = 4
+    for _ in range(2):
+        two = net(x, return_index=True)
+        assert all(torch.equal(a, b) for a, b in zip(one, two))
+    net.set_nms(0.3, 100, 40)
+    two = net(x, return_index=True)
+    net.two_stream_batch = 0
+    one = net(x, return_index=True)
+    assert all(torch.equal(a, b) for a, b in zip(one, two))
+    odd = net(x[:5])                      # odd batch: single-stream path
+    assert odd[0].shape == (5, 40, 1)

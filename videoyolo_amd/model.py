@@ -137,10 +137,18 @@ class YOLOV3(object):
         self._hybrid = False
         self._graphs = {}
         self._use_graphs = os.environ.get("VY_HIP_GRAPHS", "1") != "0"
+        # batches at least this large run as two half-batches on two streams; 0 (default) disables:
+        # measured 831 vs 830 frames/s at 608x608 batch 64 — the tail of one layer's launch is not idle
+        # enough for a second stream to matter — so it stays an opt-in experiment
+        self.two_stream_batch = int(os.environ.get("VY_TWO_STREAM_BATCH", "0"))
+        self._twin = None
         _lib.check(self._lib.vy_net_set_nms(self._h, nms_thresh, nms_topk, post_nms))
 
     def __del__(self):
         try:
+            if getattr(self, "_twin", None):
+                self._lib.vy_net_destroy(self._twin["h"])
+                self._twin = None
             if getattr(self, "_h", None):
                 self._lib.vy_net_destroy(self._h)
                 self._h = None
@@ -560,6 +568,57 @@ class YOLOV3(object):
                 self._h, ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(ids.data_ptr()),
                 ctypes.c_void_p(scores.data_ptr()), ctypes.c_void_p(bboxes.data_ptr()),
                 ctypes.c_void_p(keep.data_ptr()) if keep is not None else None, self._stream()))
+        if return_index:
+            return ids, scores, bboxes, keep
+        return ids, scores, bboxes
+
+    def detect_two_streams(self, x, return_index=False):
+        """Frames are independent, so a large batch is run as two half-batches on two HIP streams (a twin
+        vy_net that shares the parameter buffer, with its own workspace).  Every layer's launch covers a
+        non-integer number of rounds of the 512 resident blocks; with two independent launch sequences in
+        flight the last, partly filled round of one kernel overlaps with the other stream's kernels, and
+        block prologues/epilogues overlap too.  Results are identical to detect()."""
+        torch = _torch()
+        x = self._as_input(x)
+        b, _, h, w = x.shape
+        if b < 2 or b % 2:
+            return self.detect(x, return_index=return_index)
+        hb = b // 2
+        with torch.cuda.device(self._device):
+            self._ensure_plan(hb, h, w)
+            tw = getattr(self, "_twin", None)
+            if tw is None or tw["dev"] is not self._dev_params:
+                th = ctypes.c_void_p()
+                _lib.check(self._lib.vy_net_create(len(self._classes), ctypes.byref(th)))
+                _lib.check(self._lib.vy_net_bind_params(th, ctypes.c_void_p(self._dev_params.data_ptr())))
+                tw = self._twin = dict(h=th, dev=self._dev_params, ws=None, plan=None,
+                                       stream=torch.cuda.Stream(device=self._device))
+            _lib.check(self._lib.vy_net_set_nms(tw["h"], self.nms_thresh, self.nms_topk, self.post_nms))
+            cur = torch.cuda.current_stream(self._device)
+            if tw["plan"] != (hb, h, w):
+                need = self._lib.vy_net_workspace_bytes(tw["h"], hb, h, w)
+                if tw["ws"] is None or tw["ws"].numel() < need:
+                    tw["ws"] = torch.empty(need, dtype=torch.uint8, device=self._device)
+                _lib.check(self._lib.vy_net_bind_workspace(tw["h"], ctypes.c_void_p(tw["ws"].data_ptr()),
+                                                           tw["ws"].numel(), hb, h, w, ctypes.c_void_p(cur.cuda_stream)))
+                tw["plan"] = (hb, h, w)
+            rows = self.post_nms if self.post_nms > 0 else self.nms_topk
+            ids = torch.empty((b, rows, 1), dtype=torch.float32, device=self._device)
+            scores = torch.empty((b, rows, 1), dtype=torch.float32, device=self._device)
+            bboxes = torch.empty((b, rows, 4), dtype=torch.float32, device=self._device)
+            keep = torch.empty((b, rows), dtype=torch.int32, device=self._device) if return_index else None
+            side = tw["stream"]
+            side.wait_stream(cur)  # inputs, workspace zeroing and the output allocations are ordered before it
+            for half, (hnd, st) in enumerate(((self._h, cur), (tw["h"], side))):
+                lo = half * hb
+                _lib.check(self._lib.vy_net_forward_infer(
+                    hnd, ctypes.c_void_p(x[lo:].data_ptr()), ctypes.c_void_p(ids[lo:].data_ptr()),
+                    ctypes.c_void_p(scores[lo:].data_ptr()), ctypes.c_void_p(bboxes[lo:].data_ptr()),
+                    ctypes.c_void_p(keep[lo:].data_ptr()) if keep is not None else None,
+                    ctypes.c_void_p(st.cuda_stream)))
+            cur.wait_stream(side)
+            for t in (x, ids, scores, bboxes) + ((keep,) if keep is not None else ()):
+                t.record_stream(side)
         if return_index:
             return ids, scores, bboxes, keep
         return ids, scores, bboxes
