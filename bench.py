@@ -174,7 +174,7 @@ def main():
             result["roofline"]["decode_nms"] = {
                 "ms": tail[1], "algorithmic_GBps": tail[3] / (tail[1] * 1e-3) / 1e9, "hbm_peak_GBps": HBM_PEAK_GBS}
 
-    if rank == 0 and args.cpu_frames > 0:
+    if rank == 0 and world == 1 and args.cpu_frames > 0:
         # CPU baseline: the oracle (a port of the same algorithm; NOT the reference's MXNet path,
         # which cannot be installed here) on a bounded sample of the same workload
         from oracle import yolo3_oracle as O
