@@ -124,3 +124,25 @@ def test_modes_and_errors_without_device(voc_classes):
         net(np.zeros((1, 3, 64, 64), np.float32))
     with pytest.raises(RuntimeError):
         net.collect_params().reset_ctx("cpu")                                   # no CPU path
+
+
+def test_mxnet_params_container_roundtrip(voc_classes, tmp_path):
+    """save_parameters(format='mxnet') / load_parameters sniffing.  The container layout is restated
+    from memory (videoyolo_amd/mxparams.py, UNVERIFIED against mxnet): this only proves the reader and the
+    writer agree with each other and with the documented byte layout of the header."""
+    import struct
+    net = _net(voc_classes[:3])
+    net.initialize(init="synthetic", seed=7)
+    f = str(tmp_path / "net.params")
+    net.save_parameters(f, format="mxnet")
+    raw = open(f, "rb").read()
+    assert struct.unpack_from("<QQQ", raw, 0) == (0x112, 0, 366)
+    assert struct.unpack_from("<IiI", raw, 24) == (0xF993FAC9, 0, 4)          # first tensor: V2, dense, 4-D
+    assert struct.unpack_from("<4q", raw, 36) == (32, 3, 3, 3)                  # stages.0.0.0.weight OIHW
+    twin = _net(voc_classes[:3])
+    twin.load_parameters(f)
+    for k, p in net.collect_params().items():
+        assert np.array_equal(p.data(), twin.collect_params()[k].data())
+    from videoyolo_amd import mxparams
+    d = mxparams.load(f)
+    assert list(d)[0] == "stages.0.0.0.weight" and d["yolo_outputs.2.prediction.bias"].shape == (24,)

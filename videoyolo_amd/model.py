@@ -251,17 +251,28 @@ class YOLOV3(object):
         for i, p in enumerate(self._params.values()):
             self._set_param(i, vals[p.name])
 
-    def save_parameters(self, filename):
-        """Container: numpy .npz keyed by gluon structural names, reference layouts.  (The
-        reference writes mxnet's NDArray-dict format, which cannot be produced or validated
-        offline; see INTEGRATION.md.)"""
+    def save_parameters(self, filename, format=None):
+        """Gluon structural names, reference layouts.  Container: numpy .npz by default; mxnet's
+        NDArray-dict layout with ``format='mxnet'`` (videoyolo_amd.mxparams: restated from memory,
+        unverified against a real mxnet build — see INTEGRATION.md)."""
         arrays = {p.name: self._get_param(p.index) for p in self._params.values()}
+        if format == "mxnet":
+            from . import mxparams
+            mxparams.save(filename, arrays)
+            return
         with open(filename, "wb") as f:
             np.savez(f, **arrays)
 
     def load_parameters(self, filename, ctx=None, allow_missing=False, ignore_extra=False):
-        with np.load(filename) as z:
-            loaded = {k: z[k] for k in z.files}
+        """Accepts both containers (sniffed from the first bytes: zip = .npz, 0x112 = mxnet list)."""
+        with open(filename, "rb") as f:
+            head = f.read(8)
+        if head[:2] == b"PK":
+            with np.load(filename) as z:
+                loaded = {k: z[k] for k in z.files}
+        else:
+            from . import mxparams
+            loaded = mxparams.load(filename)
         self.set_parameters(loaded, allow_missing=allow_missing, ignore_extra=ignore_extra)
         if ctx is not None:
             self.reset_ctx(ctx)
