@@ -163,7 +163,8 @@ def main():
             pm = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_infer608_b64_pmc_hbm.json")))
             if pm:
                 try:
-                    k = json.load(open(pm[-1]))["kernels"].get("void conv_igemm_kernel<128, 128, 2, 2, false>")
+                    ks = json.load(open(pm[-1]))["kernels"]
+                    k = next((v for n, v in ks.items() if n.startswith("void conv_igemm_kernel<128, 128, 2, 2, false")), None)
                     if k:
                         result["roofline"]["traffic"] = k["hbm_MB_per_launch"] * 1e6
                         result["roofline"]["traffic_source"] = os.path.basename(pm[-1])
