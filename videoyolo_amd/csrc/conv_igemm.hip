@@ -503,6 +503,8 @@ hipError_t vy_launch_conv_igemm(const ConvArgs& a_in, hipStream_t s) {
   if (a.dgrad && (a.N % 4 != 0)) return hipErrorInvalidValue;
   int bm, bn;
   select_cfg(a, &bm, &bn);
+  static const int ring = getenv("VY_CONV_RING") ? atoi(getenv("VY_CONV_RING")) : 0;
+  if (ring && !a.dgrad && bn >= 64 && bm <= 128) return vy_launch_conv_ring(a, bm, bn, s);
   if (bn == 32) return launch_cfg<128, 32, 4, 1>(a, s);
   if (bm == 128 && bn == 64) return launch_cfg<128, 64, 2, 2>(a, s);
   if (bm == 64) return launch_cfg<64, 64, 2, 2>(a, s);

@@ -41,6 +41,7 @@ struct ConvArgs {
 // 3x3/1x1 implicit-GEMM convolution on v_mfma_f32_32x32x2_f32.
 hipError_t vy_launch_conv_igemm(const ConvArgs& a, hipStream_t s);
 int vy_conv_tiles_m(const ConvArgs& a);
+hipError_t vy_launch_conv_ring(const ConvArgs& a, int bm, int bn, hipStream_t s);  // conv_ring.hip
 void vy_conv_cfg(const ConvArgs& a, int* bm, int* bn);  // block tile the launch will use
 
 // stem: 3x3 stride-1 conv from the caller's NCHW image (Cin = 3) into a plane, fused affine+leaky.
