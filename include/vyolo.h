@@ -134,6 +134,13 @@ typedef struct vy_launch_stat {
 int vy_net_profile_infer(vy_net* net, const float* x, float* ids, float* scores, float* bboxes,
                          vy_launch_stat* stats, int32_t* n, void* stream);
 
+/* A HIP stream owned by the caller and created by the library (hipStreamCreateWithFlags, non-blocking):
+ * its own hardware queue, for callers that run two launch sequences side by side — the reference's
+ * `for x in data:` loop over per-device batches (detect_yolo3.py:211-222) on ONE device's two half
+ * batches.  (torch's pooled streams may share the default stream's queue.) */
+int vy_stream_create(void** stream);
+int vy_stream_destroy(void* stream);
+
 /* Frame pre-processing in front of the path: (batch,H,W,3) uint8 HWC device
  * frames -> (batch,3,H,W) fp32 NCHW, y = (x/255 - mean[c]) / std[c] — mx.nd.image.to_tensor +
  * mx.nd.image.normalize at models/definitions/yolo/transforms.py:331-334.  mean3/std3 are host

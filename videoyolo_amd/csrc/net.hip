@@ -231,4 +231,20 @@ int vy_net_profile_infer(vy_net* net, const float* x, float* ids, float* scores,
   return rc;
 }
 
+int vy_stream_create(void** stream) {
+  if (!stream) return fail(VY_ERR_INVALID, "null argument");
+  hipStream_t s = nullptr;
+  hipError_t e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+  if (e != hipSuccess) return fail(VY_ERR_HIP, "hipStreamCreateWithFlags: %s", hipGetErrorString(e));
+  *stream = s;
+  return 0;
+}
+
+int vy_stream_destroy(void* stream) {
+  if (!stream) return 0;
+  hipError_t e = hipStreamDestroy(static_cast<hipStream_t>(stream));
+  if (e != hipSuccess) return fail(VY_ERR_HIP, "hipStreamDestroy: %s", hipGetErrorString(e));
+  return 0;
+}
+
 }  // extern "C"

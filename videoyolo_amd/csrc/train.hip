@@ -139,12 +139,36 @@ size_t train_plan(vy_net* net, int b, int h, int w, bool commit) {
     if (!c.is_stem) {
       const int Ntot = c.k * c.k * c.cin;
       const int tiles = ((c.cout + 127) / 128) * ((Ntot + 127) / 128);
-      long long sp = (1024 + tiles - 1) / tiles;
-      const long long maxsp = (M + 255) / 256;
-      if (sp > maxsp) sp = maxsp;
-      if (sp < 1) sp = 1;
-      long long k = ((M + sp - 1) / sp + 31) / 32 * 32;
-      sp = (M + k - 1) / k;
+      // Split-K so that the launch fills whole rounds of the 512 resident blocks (2 per CU): the blocks
+      // of one launch are equally long, so 1026 blocks cost three rounds where 1008 cost two.  Take the
+      // fewest rounds whose fill is within 4 % of the best (fewer splits = less slab traffic); a split
+      // is at least 128 pixels (4 k-steps).
+      static const int max_rounds = getenv("VY_WGRAD_ROUNDS") ? atoi(getenv("VY_WGRAD_ROUNDS")) : 4;
+      long long sp = 1, k = ((M + 31) / 32) * 32;
+      double best = -1.0;
+      if (max_rounds == 0) {  // previous heuristic: >= 1024 blocks
+        sp = (1024 + tiles - 1) / tiles;
+        const long long maxsp = (M + 255) / 256;
+        if (sp > maxsp) sp = maxsp;
+        if (sp < 1) sp = 1;
+        k = ((M + sp - 1) / sp + 31) / 32 * 32;
+        sp = (M + k - 1) / k;
+      }
+      for (int r = 1; r <= max_rounds; ++r) {
+        long long s = (512LL * r) / tiles;
+        const long long maxsp = (M + 127) / 128;
+        if (s > maxsp) s = maxsp;
+        if (s < 1) s = 1;
+        const long long k2 = ((M + s - 1) / s + 31) / 32 * 32;
+        const long long s2 = (M + k2 - 1) / k2;
+        const long long blocks = tiles * s2;
+        const double fill = (double)blocks / (double)(((blocks + 511) / 512) * 512);
+        if (fill > best + 0.04) {
+          best = fill;
+          sp = s2;
+          k = k2;
+        }
+      }
       splits[i] = (int)sp;
       kps[i] = (int)k;
       const size_t sl = (size_t)sp * c.cout * Ntot;

@@ -170,7 +170,40 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
   dst[i] = s;
 }
 
+// Many slabs over a small weight tensor (the early layers: up to ~500 slabs of a few thousand floats):
+// a thread per element would walk the slabs serially, so G thread groups each add every G-th slab of 32
+// columns and the G partial sums are combined in group order (still a fixed order: deterministic).
+template <int G>
+__global__ __launch_bounds__(32 * G) void slab_reduce_wide_kernel(const float* __restrict__ slabs, int splits, long long n,
+                                                                  float* __restrict__ dst) {
+  __shared__ float part[G][33];
+  const int col = threadIdx.x & 31, g = threadIdx.x >> 5;
+  const long long i = (long long)blockIdx.x * 32 + col;
+  float s0 = 0.0f, s1 = 0.0f;
+  if (i < n) {
+    int k = g;
+    for (; k + G < splits; k += 2 * G) {
+      s0 += slabs[(long long)k * n + i];
+      s1 += slabs[(long long)(k + G) * n + i];
+    }
+    if (k < splits) s0 += slabs[(long long)k * n + i];
+  }
+  part[g][col] = s0 + s1;
+  __syncthreads();
+  if (g == 0 && i < n) {
+    float s = 0.0f;
+#pragma unroll
+    for (int q = 0; q < G; ++q) s += part[q][col];
+    dst[i] = s;
+  }
+}
+
 hipError_t vy_launch_slab_reduce(const float* slabs, int splits, long long n, float* dst, hipStream_t s) {
-  hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, slabs, splits, n, dst);
+  if (splits >= 64)
+    hipLaunchKernelGGL(slab_reduce_wide_kernel<32>, dim3((unsigned)((n + 31) / 32)), dim3(1024), 0, s, slabs, splits, n, dst);
+  else if (splits >= 12)
+    hipLaunchKernelGGL(slab_reduce_wide_kernel<8>, dim3((unsigned)((n + 31) / 32)), dim3(256), 0, s, slabs, splits, n, dst);
+  else
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, slabs, splits, n, dst);
   return hipGetLastError();
 }

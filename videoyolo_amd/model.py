@@ -137,9 +137,9 @@ class YOLOV3(object):
         self._hybrid = False
         self._graphs = {}
         self._use_graphs = os.environ.get("VY_HIP_GRAPHS", "1") != "0"
-        # batches at least this large run as two half-batches on two streams; 0 (default) disables:
-        # measured 831 vs 830 frames/s at 608x608 batch 64 — the tail of one layer's launch is not idle
-        # enough for a second stream to matter — so it stays an opt-in experiment
+        # batches at least this large run as two half-batches on two streams (two hardware queues);
+        # 0 (default) disables: measured 838 vs 828 frames/s at 608x608 batch 64 (+1.2 %, +2.6 % at
+        # 416x416) — launch tails are mostly not idle — for a second workspace binding, so it is opt-in
         self.two_stream_batch = int(os.environ.get("VY_TWO_STREAM_BATCH", "0"))
         self._twin = None
         _lib.check(self._lib.vy_net_set_nms(self._h, nms_thresh, nms_topk, post_nms))
@@ -148,6 +148,8 @@ class YOLOV3(object):
         try:
             if getattr(self, "_twin", None):
                 self._lib.vy_net_destroy(self._twin["h"])
+                if self._twin.get("raw_stream"):
+                    self._lib.vy_stream_destroy(self._twin["raw_stream"])
                 self._twin = None
             if getattr(self, "_h", None):
                 self._lib.vy_net_destroy(self._h)
@@ -461,6 +463,8 @@ class YOLOV3(object):
                     raise ValueError("training call: net(x, gt_boxes, obj_t, centers_t, scales_t, weights_t, clas_t)")
                 return self.forward_train(x, *args)
             return self.forward_train_mode(x)
+        if self.two_stream_batch and len(x) >= self.two_stream_batch and not getattr(self, "_hybrid", False):
+            return self.detect_two_streams(x, return_index=return_index)
         return self.detect(x, return_index=return_index)
 
     def _dev(self, a):
@@ -602,8 +606,12 @@ class YOLOV3(object):
                 th = ctypes.c_void_p()
                 _lib.check(self._lib.vy_net_create(len(self._classes), ctypes.byref(th)))
                 _lib.check(self._lib.vy_net_bind_params(th, ctypes.c_void_p(self._dev_params.data_ptr())))
-                tw = self._twin = dict(h=th, dev=self._dev_params, ws=None, plan=None,
-                                       stream=torch.cuda.Stream(device=self._device))
+                # a stream of the library's own: torch's pooled streams may share the default stream's
+                # hardware queue, in which case the two launch sequences would simply alternate
+                sp = ctypes.c_void_p()
+                _lib.check(self._lib.vy_stream_create(ctypes.byref(sp)))
+                tw = self._twin = dict(h=th, dev=self._dev_params, ws=None, plan=None, raw_stream=sp,
+                                       stream=torch.cuda.ExternalStream(sp.value, device=self._device))
             _lib.check(self._lib.vy_net_set_nms(tw["h"], self.nms_thresh, self.nms_topk, self.post_nms))
             cur = torch.cuda.current_stream(self._device)
             if tw["plan"] != (hb, h, w):
