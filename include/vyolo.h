@@ -149,6 +149,18 @@ int vy_stream_destroy(void* stream);
 int vy_preprocess_frames(const uint8_t* frames_hwc, float* out_nchw, int32_t batch, int32_t height,
                          int32_t width, const float* mean3, const float* std3, void* stream);
 
+/* Prefetch target generation on the device: YOLOV3PrefetchTargetGenerator.forward,
+ * models/definitions/yolo/yolo_target.py:31-148 (called per sample from the DataLoader transform,
+ * transforms.py:259-277), for a whole batch.  gt_boxes (batch,num_gt,4) corner pixels of the
+ * (height,width) network input, gt_ids (batch,num_gt) class index as fp32, gt_mixratio (batch,num_gt)
+ * or NULL; a row with any negative coordinate ends that image's list (:107-108).  Outputs, all fp32
+ * device buffers fully written: objness_t (batch,N,1), centers_t / scales_t / weights_t (batch,N,2),
+ * clas_t (batch,N,num_class), N = vy_net_num_anchors order (stride 32,16,8 -> cell -> anchor) — exactly
+ * the five tensors vy_net_train_forward takes.  Anchors are the yolo3_darknet53 table (wrappers.py:80-84). */
+int vy_prefetch_targets(const float* gt_boxes, const float* gt_ids, const float* gt_mixratio, int32_t batch,
+                        int32_t num_gt, int32_t height, int32_t width, int32_t num_class, float* objness_t,
+                        float* centers_t, float* scales_t, float* weights_t, float* clas_t, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Training step.  Reference call pattern, train_yolov3.py:623-634:
  *     with autograd.record():

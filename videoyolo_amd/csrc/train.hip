@@ -143,7 +143,7 @@ size_t train_plan(vy_net* net, int b, int h, int w, bool commit) {
       // of one launch are equally long, so 1026 blocks cost three rounds where 1008 cost two.  Take the
       // fewest rounds whose fill is within 4 % of the best (fewer splits = less slab traffic); a split
       // is at least 128 pixels (4 k-steps).
-      static const int max_rounds = getenv("VY_WGRAD_ROUNDS") ? atoi(getenv("VY_WGRAD_ROUNDS")) : 4;
+      static const int max_rounds = getenv("VY_WGRAD_ROUNDS") ? atoi(getenv("VY_WGRAD_ROUNDS")) : 0;
       long long sp = 1, k = ((M + 31) / 32) * 32;
       double best = -1.0;
       if (max_rounds == 0) {  // previous heuristic: >= 1024 blocks
@@ -676,7 +676,15 @@ int vy_net_bind_train(vy_net* net, void* dev_ws, size_t bytes, int32_t batch, in
   HIP_TRY(hipMemsetAsync(dev_ws, 0, need, s));
   static const int use_side = getenv("VY_TRAIN_SIDE_STREAM") ? atoi(getenv("VY_TRAIN_SIDE_STREAM")) : 1;
   if (use_side && !t->side) {
-    HIP_TRY(hipStreamCreateWithFlags(&t->side, hipStreamNonBlocking));
+    // VY_TRAIN_SIDE_PRIO: 0 default priority, 1 lowest (the weight gradients only fill what the
+    // BatchNorm / dgrad chain on the caller's stream leaves idle), -1 highest
+    static const int prio = getenv("VY_TRAIN_SIDE_PRIO") ? atoi(getenv("VY_TRAIN_SIDE_PRIO")) : 0;
+    int least = 0, greatest = 0;
+    HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    if (prio == 0)
+      HIP_TRY(hipStreamCreateWithFlags(&t->side, hipStreamNonBlocking));
+    else
+      HIP_TRY(hipStreamCreateWithPriority(&t->side, hipStreamNonBlocking, prio > 0 ? least : greatest));
     HIP_TRY(hipEventCreateWithFlags(&t->ev_main, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&t->ev_side, hipEventDisableTiming));
   }

@@ -12,6 +12,8 @@
 // the MFMA fragments A[i=o][k=p], B[k=p][j=n] are ds_read_b32 of 32 consecutive floats per
 // half-wave (conflict-free, no swizzle).  Block tile 128(o) x 128(n) x 32(p), 4 waves 2x2,
 // 64 accumulator VGPRs per lane, 64 KiB LDS double buffer -> 2 blocks / CU.
+#include <cstdlib>
+
 #include "kernels.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -199,7 +201,10 @@ __global__ __launch_bounds__(32 * G) void slab_reduce_wide_kernel(const float* _
 }
 
 hipError_t vy_launch_slab_reduce(const float* slabs, int splits, long long n, float* dst, hipStream_t s) {
-  if (splits >= 64)
+  static const int wide = getenv("VY_SLAB_WIDE") ? atoi(getenv("VY_SLAB_WIDE")) : 1;
+  if (!wide)
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, slabs, splits, n, dst);
+  else if (splits >= 64)
     hipLaunchKernelGGL(slab_reduce_wide_kernel<32>, dim3((unsigned)((n + 31) / 32)), dim3(1024), 0, s, slabs, splits, n, dst);
   else if (splits >= 12)
     hipLaunchKernelGGL(slab_reduce_wide_kernel<8>, dim3((unsigned)((n + 31) / 32)), dim3(256), 0, s, slabs, splits, n, dst);

@@ -24,10 +24,14 @@ class YOLOV3PrefetchTargetGenerator(object):
     def __init__(self, num_class):
         self._num_class = num_class
 
-    def __call__(self, height, width, gt_boxes, gt_ids, gt_mixratio=None):
+    def __call__(self, height, width, gt_boxes, gt_ids, gt_mixratio=None, device=None):
         """gt_boxes (B,M,4) corner pixels, gt_ids (B,M,1), -1 rows = padding.
+        numpy inputs and device=None: the DataLoader-worker variant below (numpy in, numpy out, like
+        the reference); device tensors or device='cuda:N': the HIP kernel (`on_device`).
         Returns objectness (B,N,1), center_targets (B,N,2), scale_targets (B,N,2), weights (B,N,2),
         class_targets (B,N,C) in the order the training forward expects (stride 32,16,8; cell; anchor)."""
+        if device is not None or _is_device_tensor(gt_boxes):
+            return self.on_device(height, width, gt_boxes, gt_ids, gt_mixratio, device=device)
         gt_boxes = np.asarray(gt_boxes, np.float32)
         gt_ids = np.asarray(gt_ids, np.float32)
         B, M = gt_boxes.shape[:2]
@@ -77,6 +81,37 @@ class YOLOV3PrefetchTargetGenerator(object):
                 cls[b, n, :] = 0
                 cls[b, n, int(gt_ids[b, m, 0])] = 1
         return obj, ctr, scl, wts, cls
+
+    def on_device(self, height, width, gt_boxes, gt_ids, gt_mixratio=None, device=None):
+        """The same five tensors built on the GPU by libvyolo's vy_prefetch_targets (csrc/targets.hip):
+        a fill launch + one scatter launch for the whole batch; the outputs stay in HBM for the training
+        call.  Inputs may be numpy arrays or device tensors; returns torch device tensors."""
+        import ctypes
+        import torch
+        from . import _lib
+        lib = _lib.load()
+        dev = torch.device(device) if device is not None else gt_boxes.device
+        gb = torch.as_tensor(gt_boxes, dtype=torch.float32).to(dev).contiguous()
+        B, M = int(gb.shape[0]), int(gb.shape[1])
+        gi = torch.as_tensor(gt_ids, dtype=torch.float32).to(dev).contiguous().reshape(B, M)
+        gm = None
+        if gt_mixratio is not None:
+            gm = torch.as_tensor(gt_mixratio, dtype=torch.float32).to(dev).contiguous().reshape(B, M)
+        C, N = self._num_class, num_anchors(height, width)
+        out = [torch.empty((B, N, k), dtype=torch.float32, device=dev) for k in (1, 2, 2, 2, C)]
+
+        def ptr(t):
+            return ctypes.c_void_p(t.data_ptr()) if t is not None and t.numel() else None
+
+        with torch.cuda.device(dev):
+            _lib.check(lib.vy_prefetch_targets(ptr(gb), ptr(gi), ptr(gm), B, M, int(height), int(width), C,
+                                               *[ptr(t) for t in out],
+                                               ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+        return tuple(out)
+
+
+def _is_device_tensor(a):
+    return type(a).__module__.startswith("torch") and getattr(a, "is_cuda", False)
 
 
 def synthetic_gt(batch, size, num_class, m=8, seed=0):
