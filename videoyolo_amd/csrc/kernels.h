@@ -118,6 +118,8 @@ struct BnFinalizeArgs {
   float eps, momentum;
 };
 hipError_t vy_launch_bn_finalize(const BnFinalizeArgs& a, hipStream_t s);
+// ordered reduce of the [n_part][2][C] partial sums + finalize in one launch (per-device BatchNorm)
+hipError_t vy_launch_bn_reduce_finalize(const double* partials, int n_part, const BnFinalizeArgs& a, hipStream_t s);
 
 // a = leaky(fma(z, scale, shift)) (+ res), z plane (B,H+2,W+2,C) -> output view (x1 or x2 replicate)
 struct BnApplyArgs {
@@ -162,6 +164,7 @@ struct BnBwdFinalizeArgs {
   const double* local_sums;
 };
 hipError_t vy_launch_bn_bwd_finalize(const BnBwdFinalizeArgs& a, hipStream_t s);
+hipError_t vy_launch_bn_bwd_reduce_finalize(const float* partials, int n_part, const BnBwdFinalizeArgs& a, hipStream_t s);
 hipError_t vy_launch_bn_bwd_apply(const BnBwdArgs& a, hipStream_t s);
 
 // per-channel sums of a plane view over all pixels -> partials [n_chunks][C] (prediction-conv bias grad)

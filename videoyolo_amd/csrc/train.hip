@@ -77,6 +77,14 @@ size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 constexpr int kBwdChunk = 64;  // pixels per partial-sum block of the BN-backward / bias-gradient reductions
 
+// BN-backward partial sums: 64 pixels per block on the small maps (enough blocks to fill the chip), more
+// on the large ones so that the ordered second stage stays at <= ~1024 rows
+inline int bwd_chunk(long long npix) {
+  static const int adaptive = getenv("VY_BWD_CHUNK_ADAPT") ? atoi(getenv("VY_BWD_CHUNK_ADAPT")) : 1;
+  if (!adaptive || npix <= 64 * 1024) return kBwdChunk;
+  return (int)(((npix / 1024) + 63) / 64 * 64);
+}
+
 bool is_sync_layer(const ConvT& c) {
   // the layers Darknet3D builds with the passed norm_layer: the stem and the stride-2 convs
   // (three_darknet.py:163-181); every other BatchNorm in the model is a plain per-device one
@@ -325,11 +333,16 @@ int forward_train(const TrainCtx& c, const float* x) {
       n_part = vy_conv_tiles_m(a);
     }
     const int C = cv.cout;
-    HIP_TRY(vy_launch_reduce_partials_f64(reinterpret_cast<const double*>(c.partials()), n_part, 2 * C,
-                                          c.sums_local(), c.s));
+    // statistics exchange between ranks only for the SyncBatchNorm layers; everywhere else the ordered
+    // reduce of the per-tile sums and the finalize are one launch
+    const bool exchange = c.t->world > 1 && is_sync_layer(cv);
     double count = (double)B * zp.H * zp.W;
-    const double* use_sums;
-    if (int rc = combine_sums(c, cv, 2 * C, &count, &use_sums)) return rc;
+    const double* use_sums = nullptr;
+    if (exchange) {
+      HIP_TRY(vy_launch_reduce_partials_f64(reinterpret_cast<const double*>(c.partials()), n_part, 2 * C,
+                                            c.sums_local(), c.s));
+      if (int rc = combine_sums(c, cv, 2 * C, &count, &use_sums)) return rc;
+    }
     BnFinalizeArgs f;
     f.sums = use_sums;
     f.count = count;
@@ -344,7 +357,10 @@ int forward_train(const TrainCtx& c, const float* x) {
     f.C = C;
     f.eps = 1e-5f;
     f.momentum = 0.9f;  // layers.py:68
-    HIP_TRY(vy_launch_bn_finalize(f, c.s));
+    if (exchange)
+      HIP_TRY(vy_launch_bn_finalize(f, c.s));
+    else
+      HIP_TRY(vy_launch_bn_reduce_finalize(reinterpret_cast<const double*>(c.partials()), n_part, f, c.s));
     BnApplyArgs ap;
     memset(&ap, 0, sizeof ap);
     ap.z = c.zplane((int)ci);
@@ -570,12 +586,15 @@ int backward_train(const TrainCtx& c, const float* x) {
       bb.g_cs = op.C;
       bb.g_co = cv.out_co;
       bb.ups = cv.ups;
-      bb.chunk = kBwdChunk;
+      bb.chunk = bwd_chunk((long long)B * zp.H * zp.W);
       HIP_TRY(vy_launch_bn_bwd_reduce(bb, c.s));
-      HIP_TRY(vy_launch_reduce_partials(c.partials(), vy_bn_bwd_chunks(bb), 2 * cv.cout, c.sums_local(), c.s));
+      const bool exchange = c.t->world > 1 && is_sync_layer(cv);
       double count = (double)B * zp.H * zp.W;
-      const double* use_sums;
-      if (int rc = combine_sums(c, cv, 2 * cv.cout, &count, &use_sums)) return rc;
+      const double* use_sums = nullptr;
+      if (exchange) {
+        HIP_TRY(vy_launch_reduce_partials(c.partials(), vy_bn_bwd_chunks(bb), 2 * cv.cout, c.sums_local(), c.s));
+        if (int rc = combine_sums(c, cv, 2 * cv.cout, &count, &use_sums)) return rc;
+      }
       BnBwdFinalizeArgs f;
       memset(&f, 0, sizeof f);
       f.sums = use_sums;
@@ -587,7 +606,10 @@ int backward_train(const TrainCtx& c, const float* x) {
       f.dbeta = c.grad_of(cv.p_beta);
       f.coef = c.coef();
       f.C = cv.cout;
-      HIP_TRY(vy_launch_bn_bwd_finalize(f, c.s));
+      if (exchange)
+        HIP_TRY(vy_launch_bn_bwd_finalize(f, c.s));
+      else
+        HIP_TRY(vy_launch_bn_bwd_reduce_finalize(c.partials(), vy_bn_bwd_chunks(bb), f, c.s));
       HIP_TRY(vy_launch_bn_bwd_apply(bb, c.s));
       dzp = c.zplane(ci);
       dz_cs = zp.C;

@@ -60,11 +60,9 @@ hipError_t vy_launch_f64_to_f32(const double* src, float* dst, int n, hipStream_
 }
 
 // ------------------------------------------------------------------------------------------------
-__global__ void bn_finalize_kernel(const BnFinalizeArgs a) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= a.C) return;
-  const double mean = a.sums[c] / a.count;
-  double var = a.sums[a.C + c] / a.count - mean * mean;  // biased (mxnet BatchNorm)
+__device__ __forceinline__ void bn_finalize_channel(const BnFinalizeArgs& a, int c, double sum1, double sum2) {
+  const double mean = sum1 / a.count;
+  double var = sum2 / a.count - mean * mean;  // biased (mxnet BatchNorm)
   if (var < 0.0) var = 0.0;
   const float mf = (float)mean, vf = (float)var;
   const float invstd = 1.0f / sqrtf(vf + a.eps);
@@ -75,6 +73,51 @@ __global__ void bn_finalize_kernel(const BnFinalizeArgs a) {
   a.save_invstd[c] = invstd;
   a.running_mean[c] = a.running_mean[c] * a.momentum + mf * (1.0f - a.momentum);
   a.running_var[c] = a.running_var[c] * a.momentum + vf * (1.0f - a.momentum);
+}
+
+__global__ void bn_finalize_kernel(const BnFinalizeArgs a) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= a.C) return;
+  bn_finalize_channel(a, c, a.sums[c], a.sums[a.C + c]);
+}
+
+// Per-device BatchNorm (no statistics exchange between the reduce and the finalize): both in one launch.
+// Block = 32 channels x 32 row groups, the same summation tree as reduce_partials_kernel, for the
+// channel's two columns (sum, sum of squares) at once.
+template <typename T, typename Args, typename Fin>
+__device__ __forceinline__ void reduce2_finalize(const T* __restrict__ partials, int n_part, const Args& a, Fin fin) {
+  __shared__ double red[2][32][33];
+  const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cx;
+  double acc1 = 0.0, acc2 = 0.0;
+  if (c < a.C)
+    for (int t = ry; t < n_part; t += 32) {
+      acc1 += (double)partials[(long long)t * 2 * a.C + c];
+      acc2 += (double)partials[(long long)t * 2 * a.C + a.C + c];
+    }
+  red[0][ry][cx] = acc1;
+  red[1][ry][cx] = acc2;
+  __syncthreads();
+  if (ry == 0 && c < a.C) {
+    double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+    for (int r = 0; r < 32; ++r) {
+      s1 += red[0][r][cx];
+      s2 += red[1][r][cx];
+    }
+    fin(a, c, s1, s2);
+  }
+}
+
+__global__ __launch_bounds__(1024) void bn_reduce_finalize_kernel(const double* __restrict__ partials, int n_part,
+                                                                  const BnFinalizeArgs a) {
+  reduce2_finalize(partials, n_part, a,
+                   [](const BnFinalizeArgs& f, int c, double s1, double s2) { bn_finalize_channel(f, c, s1, s2); });
+}
+
+hipError_t vy_launch_bn_reduce_finalize(const double* partials, int n_part, const BnFinalizeArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(bn_reduce_finalize_kernel, dim3((a.C + 31) / 32), dim3(1024), 0, s, partials, n_part, a);
+  return hipGetLastError();
 }
 
 hipError_t vy_launch_bn_finalize(const BnFinalizeArgs& a, hipStream_t s) {
@@ -202,15 +245,33 @@ hipError_t vy_launch_bn_bwd_reduce(const BnBwdArgs& a, hipStream_t s) {
   return hipGetLastError();
 }
 
+__device__ __forceinline__ void bn_bwd_finalize_channel(const BnBwdFinalizeArgs& a, int c, double l1, double l2,
+                                                        double g1, double g2) {
+  a.dbeta[c] = (float)l1;   // local sums (SyncBN: all-reduced later with the other gradients)
+  a.dgamma[c] = (float)l2;
+  a.coef[c] = a.gamma[c] * a.save_invstd[c];
+  a.coef[a.C + c] = (float)(g1 / a.count);
+  a.coef[2 * a.C + c] = (float)(g2 / a.count);
+}
+
 __global__ void bn_bwd_finalize_kernel(const BnBwdFinalizeArgs a) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= a.C) return;
   const double* ls = a.local_sums ? a.local_sums : a.sums;
-  a.dbeta[c] = (float)ls[c];
-  a.dgamma[c] = (float)ls[a.C + c];
-  a.coef[c] = a.gamma[c] * a.save_invstd[c];
-  a.coef[a.C + c] = (float)(a.sums[c] / a.count);
-  a.coef[2 * a.C + c] = (float)(a.sums[a.C + c] / a.count);
+  bn_bwd_finalize_channel(a, c, ls[c], ls[a.C + c], a.sums[c], a.sums[a.C + c]);
+}
+
+__global__ __launch_bounds__(1024) void bn_bwd_reduce_finalize_kernel(const float* __restrict__ partials, int n_part,
+                                                                      const BnBwdFinalizeArgs a) {
+  reduce2_finalize(partials, n_part, a, [](const BnBwdFinalizeArgs& f, int c, double s1, double s2) {
+    bn_bwd_finalize_channel(f, c, s1, s2, s1, s2);
+  });
+}
+
+hipError_t vy_launch_bn_bwd_reduce_finalize(const float* partials, int n_part, const BnBwdFinalizeArgs& a,
+                                            hipStream_t s) {
+  hipLaunchKernelGGL(bn_bwd_reduce_finalize_kernel, dim3((a.C + 31) / 32), dim3(1024), 0, s, partials, n_part, a);
+  return hipGetLastError();
 }
 
 hipError_t vy_launch_bn_bwd_finalize(const BnBwdFinalizeArgs& a, hipStream_t s) {
