@@ -28,9 +28,13 @@ __device__ __forceinline__ void lds_dma16(const float* gptr, unsigned lds_addr) 
 #endif
 }
 
+// KP = pixels per k-step (LDS stage): 32 -> 64 KiB double buffer (2 blocks / CU), 16 -> 32 KiB (4 blocks / CU,
+// which leaves room for the concurrently running dgrad blocks of the main stream)
+template <int KP>
 __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a, const int tiles_n) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  constexpr int BM = 128, BN = 128, TILE = 32 * 128 * 4, STAGE = 2 * TILE;
+  constexpr int BM = 128, BN = 128, TILE = KP * 128 * 4, STAGE = 2 * TILE;
+  constexpr int NJ = KP / 8;  // DMA instructions per wave per operand per k-step = MFMA groups per k-step
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -44,7 +48,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a, const 
   const int p_begin = split * a.k_per_split;
   int p_end = p_begin + a.k_per_split;
   if (p_end > a.M) p_end = a.M;
-  const int T = (p_end - p_begin + 31) / 32;
+  const int T = (p_end - p_begin + KP - 1) / KP;
 
   // this lane's fixed column chunk in both tiles
   const int chunk = lane & 31;            // 16-B chunk inside a 512-B row
@@ -66,12 +70,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a, const 
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-  // Each lane stages the same 4 pixel rows of both tiles every k-step (row = 2*(j*4+wave) + h); their
-  // (b, oy, ox) are carried incrementally (+32 pixels per k-step) instead of being re-derived by
+  // Each lane stages the same NJ pixel rows of both tiles every k-step (row = 2*(j*4+wave) + h); their
+  // (b, oy, ox) are carried incrementally (+KP pixels per k-step) instead of being re-derived by
   // integer division each time.
-  int pb[4], py[4], px[4];
+  int pb[NJ], py[NJ], px[NJ];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
+  for (int j = 0; j < NJ; ++j) {
     const int p = p_begin + 2 * (j * 4 + wave) + h;
     px[j] = p % a.Wo;
     const int tt = p / a.Wo;
@@ -82,7 +86,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a, const 
   // one quarter (instruction j) of the LDS-DMA of tile t into buffer buf
   auto stage = [&](int t, int buf, int j) {
     const int q = j * 4 + wave;
-    const int p = p_begin + t * 32 + 2 * q + h;
+    const int p = p_begin + t * KP + 2 * q + h;
     const float* pa = a.zero;
     const float* pb_ = a.zero;
     if (p < p_end) {
@@ -93,8 +97,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a, const 
     }
     lds_dma16(pa, lds0 + buf * STAGE + q * 1024);
     lds_dma16(pb_, lds0 + buf * STAGE + TILE + q * 1024);
-    // advance this row by 32 pixels for the next tile
-    px[j] += 32;
+    // advance this row by KP pixels for the next tile
+    px[j] += KP;
     while (px[j] >= a.Wo) {
       px[j] -= a.Wo;
       if (++py[j] == a.Ho) {
@@ -106,16 +110,16 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a, const 
 
   if (T > 0) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) stage(0, 0, j);
+    for (int j = 0; j < NJ; ++j) stage(0, 0, j);
   }
   for (int t = 0; t < T; ++t) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of tile t has landed
     __syncthreads();
     const bool more = t + 1 < T;
     const float* tA = reinterpret_cast<const float*>(smem + (t & 1) * STAGE);
-    const float* tB = tA + 32 * 128;
+    const float* tB = tA + KP * 128;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
+    for (int g = 0; g < NJ; ++g) {
       float av[4][2], bv[4][2];
 #pragma unroll
       for (int s4 = 0; s4 < 4; ++s4) {
@@ -159,7 +163,13 @@ hipError_t vy_launch_wgrad(const WgradArgs& a, hipStream_t s) {
     return hipErrorInvalidValue;
   const int Ntot = a.k * a.k * a.Cin;
   const int tiles_m = (a.Cout + 127) / 128, tiles_n = (Ntot + 127) / 128;
-  hipLaunchKernelGGL(wgrad_kernel, dim3(tiles_m * tiles_n, a.splits), dim3(256), 0, s, a, tiles_n);
+  static const int kp = getenv("VY_WGRAD_KP") ? atoi(getenv("VY_WGRAD_KP")) : 32;
+  // experiment: unused dynamic LDS to cap the resident wgrad blocks per CU
+  static const int pad = getenv("VY_WGRAD_LDS_PAD") ? atoi(getenv("VY_WGRAD_LDS_PAD")) : 0;
+  if (kp == 16)
+    hipLaunchKernelGGL(wgrad_kernel<16>, dim3(tiles_m * tiles_n, a.splits), dim3(256), pad, s, a, tiles_n);
+  else
+    hipLaunchKernelGGL(wgrad_kernel<32>, dim3(tiles_m * tiles_n, a.splits), dim3(256), pad, s, a, tiles_n);
   return hipGetLastError();
 }
 
