@@ -53,6 +53,17 @@ __device__ __forceinline__ void lds_dma16(const float* gptr, unsigned lds_addr) 
 #endif
 }
 
+// fp32 access through a buffer descriptor (the raw_buffer builtins move 32-bit integers): byte offset
+// `voff` per lane + uniform `soff`; an offset past the descriptor's range reads 0 / is not written
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ float buf_load_f32(__amdgpu_buffer_rsrc_t rsrc, unsigned voff) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, 0, 0));
+}
+__device__ __forceinline__ void buf_store_f32(float v, __amdgpu_buffer_rsrc_t rsrc, unsigned voff, int soff) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrc, voff, soff, 0);
+}
+#endif
+
 template <int BM, int BN, int WM, int WN, bool DGRAD, int SCHED = 0>
 // 2nd launch-bounds argument = waves per SIMD the register allocation must allow: two (2 blocks/CU of 4
 // waves, or one 8-wave block).  Without it hipcc let the register count drift past 256 and silently
@@ -69,7 +80,14 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_kernel(const ConvA
   // one LDS object: [stage0 A|W][stage1 A|W][row tables]
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE + 2 * BM * 8];
   long long* in_off = reinterpret_cast<long long*>(smem + 2 * STAGE);
-  long long* o_pix = in_off + BM;
+  // epilogue row tables: byte offset of the row's output pixel (and of its addend pixel) relative to the
+  // tile's first pixel; kInvalidRow for rows past M.  The epilogue addresses memory through buffer
+  // descriptors based at the tile's first pixel: 32-bit offsets (one v_add per element instead of
+  // 64-bit multiply-adds), and an offset with bit 31 set is out of range for the descriptor, so the
+  // hardware drops the store / returns 0 for the load — no per-element branches.
+  unsigned* o_off = reinterpret_cast<unsigned*>(in_off + BM);
+  unsigned* r_off = o_off + BM;
+  constexpr unsigned kInvalidRow = 0x80000000u;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -88,6 +106,17 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_kernel(const ConvA
   const int tile_m = v / tiles_n, tile_n = v - tile_m * tiles_n;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
+  // output pixel of the tile's first row (m0 < M always): wave-uniform
+  long long pix0;
+  {
+    const int x = m0 % a.LW;
+    const int t = m0 / a.LW;
+    const int y = t % a.LH;
+    const int b = t / a.LH;
+    const long long p = (long long)(b * a.o_Hp + y * a.o_s + a.o_oy) * a.o_Wp + x * a.o_s + a.o_ox;
+    pix0 = ((long long)__builtin_amdgcn_readfirstlane((int)(p >> 32)) << 32) |
+           (unsigned)__builtin_amdgcn_readfirstlane((int)p);
+  }
   for (int rr = tid; rr < BM; rr += NT) {
     const int m = m0 + rr;
     const int mm = m < a.M ? m : a.M - 1;
@@ -96,7 +125,9 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_kernel(const ConvA
     const int y = t % a.LH;
     const int b = t / a.LH;
     in_off[rr] = ((long long)(b * a.a_Hp + y * a.a_s + a.a_oy) * a.a_Wp + x * a.a_s + a.a_ox) * a.a_cs + a.a_co;
-    o_pix[rr] = (m < a.M) ? ((long long)(b * a.o_Hp + y * a.o_s + a.o_oy) * a.o_Wp + x * a.o_s + a.o_ox) : -1;
+    const unsigned rel = (unsigned)(((long long)(b * a.o_Hp + y * a.o_s + a.o_oy) * a.o_Wp + x * a.o_s + a.o_ox) - pix0);
+    o_off[rr] = (m < a.M) ? rel * (unsigned)a.o_cs * 4u : kInvalidRow;
+    r_off[rr] = (m < a.M) ? rel * (unsigned)a.r_cs * 4u : kInvalidRow;
   }
   __syncthreads();
 
@@ -333,49 +364,80 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_kernel(const ConvA
     ktile(T - 1, std::false_type{});
   }
 
-  // epilogue: affine (folded BN or bias) -> leaky -> + addend -> store (x1 or x2-replicated).
-  // Loads of the addend are unconditional (invalid rows / columns read a clamped, valid address) so
-  // that all 16*TM of a column tile are in flight together; only the stores are predicated.
+  // epilogue: affine (folded BN or bias) -> leaky -> + addend -> store (x1 or x2-replicated), through
+  // buffer descriptors based at the tile's first pixel and column (see the row tables above)
+  constexpr int kRsrcFlags = 0x00020000;  // raw dword buffer, gfx9 data format 32
+  const __amdgpu_buffer_rsrc_t out_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(a.out + (pix0 * a.o_cs + a.o_co + n0), 0, 0x7fffffff, kRsrcFlags);
+  const __amdgpu_buffer_rsrc_t res_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.res ? a.res + (pix0 * a.r_cs + a.r_co + n0) : a.in), 0, 0x7fffffff, kRsrcFlags);
+  const int ups_dx = a.o_cs * 4, ups_dy = a.o_Wp * a.o_cs * 4;
+  // The epilogue variant (which of scale / shift / leaky / addend / x2-replicate apply) is uniform for the
+  // launch; it is resolved ONCE, outside the element loops, into a straight-line instance per combination —
+  // with the tests inside the loops hipcc emitted a branch (and a serialising wait) per element.
+  auto epilogue = [&](auto has_scale_, auto has_shift_, auto leaky_, auto has_res_, auto ups2_) {
+    constexpr bool has_scale = decltype(has_scale_)::value, has_shift = decltype(has_shift_)::value;
+    constexpr bool leaky = decltype(leaky_)::value, has_res = decltype(has_res_)::value, ups2 = decltype(ups2_)::value;
 #pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int n = n0 + (wn * TN + j) * 32 + lrow;
-    const bool nvalid = n < a.N;
-    const int nc = nvalid ? n : a.N - 1;
-    float sc = 1.0f, sh = 0.0f;
-    if (a.scale) sc = a.scale[nc];
-    if (a.shift) sh = a.shift[nc];
+    for (int j = 0; j < TN; ++j) {
+      const int ncol = (wn * TN + j) * 32 + lrow;
+      const int n = n0 + ncol;
+      const bool nvalid = n < a.N;
+      const int nc = nvalid ? n : a.N - 1;
+      const unsigned cmask = nvalid ? 0u : kInvalidRow;
+      float sc = 1.0f, sh = 0.0f;
+      if (has_scale) sc = a.scale[nc];
+      if (has_scale || has_shift) sh = a.shift[nc];
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
-      long long op[16];
-      float rv[16];
+      for (int i = 0; i < TM; ++i) {
+        unsigned oo[16];
+        float rv[16];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        op[r] = o_pix[row];
-      }
-      if (a.res) {
+        for (int r = 0; r < 16; ++r) {
+          const int row = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          oo[r] = (o_off[row] + (unsigned)ncol * 4u) | cmask;
+          if (has_res)
+            rv[r] = buf_load_f32(res_rsrc, (r_off[row] + (unsigned)ncol * 4u) | cmask);
+        }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) rv[r] = a.res[(op[r] < 0 ? 0 : op[r]) * a.r_cs + a.r_co + nc];
-      }
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        float vv = acc[i][j][r];
-        if (a.scale)
-          vv = fmaf(vv, sc, sh);
-        else if (a.shift)
-          vv = vv + sh;
-        if (a.leaky) vv = vy_leaky(vv);
-        if (a.res) vv = vv + rv[r];
-        if (op[r] >= 0 && nvalid) {
-          float* o = a.out + op[r] * a.o_cs + a.o_co + n;
-          o[0] = vv;
-          if (a.ups == 2) {
-            o[a.o_cs] = vv;
-            o[(long long)a.o_Wp * a.o_cs] = vv;
-            o[(long long)(a.o_Wp + 1) * a.o_cs] = vv;
+        for (int r = 0; r < 16; ++r) {
+          float vv = acc[i][j][r];
+          if (has_scale)
+            vv = fmaf(vv, sc, sh);
+          else if (has_shift)
+            vv = vv + sh;
+          if (leaky) vv = vy_leaky(vv);
+          if (has_res) vv = vv + rv[r];
+          buf_store_f32(vv, out_rsrc, oo[r], 0);
+          if (ups2) {
+            buf_store_f32(vv, out_rsrc, oo[r], ups_dx);
+            buf_store_f32(vv, out_rsrc, oo[r], ups_dy);
+            buf_store_f32(vv, out_rsrc, oo[r], ups_dy + ups_dx);
           }
         }
       }
+    }
+  };
+  {
+    using T = std::true_type;
+    using F = std::false_type;
+    const bool f_scale = a.scale != nullptr, f_shift = a.shift != nullptr, f_leaky = a.leaky != 0;
+    const bool f_res = a.res != nullptr, f_ups2 = a.ups == 2;
+    if (f_scale && f_shift && f_leaky && !f_ups2) {           // conv + BN + leaky (+ residual): inference cells
+      if (f_res) epilogue(T{}, T{}, T{}, T{}, F{});
+      else epilogue(T{}, T{}, T{}, F{}, F{});
+    } else if (f_scale && f_shift && f_leaky && !f_res) {     // transition cells: x2-replicated store
+      epilogue(T{}, T{}, T{}, F{}, T{});
+    } else if (!f_scale && !f_leaky && !f_ups2) {             // raw conv / bias / gradients (+ accumulate)
+      if (f_shift) {
+        if (f_res) epilogue(F{}, T{}, F{}, T{}, F{});
+        else epilogue(F{}, T{}, F{}, F{}, F{});
+      } else {
+        if (f_res) epilogue(F{}, F{}, F{}, T{}, F{});
+        else epilogue(F{}, F{}, F{}, F{}, F{});
+      }
+    } else {
+      __builtin_trap();  // no launch site builds any other combination (vy_launch_conv_igemm rejects them)
     }
   }
 
@@ -394,7 +456,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_kernel(const ConvA
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int row = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-          const double vv = o_pix[row] >= 0 ? (double)acc[i][j][r] : 0.0;
+          const double vv = o_off[row] != kInvalidRow ? (double)acc[i][j][r] : 0.0;
           s1[j] += vv;
           s2[j] += vv * vv;
         }
@@ -501,6 +563,10 @@ hipError_t vy_launch_conv_igemm(const ConvArgs& a_in, hipStream_t s) {
   }
   if (a.Kc % 32 != 0 || a.ntaps < 1 || a.ntaps > 9 || a.M <= 0 || a.N <= 0) return hipErrorInvalidValue;
   if (a.dgrad && (a.N % 4 != 0)) return hipErrorInvalidValue;
+  {  // epilogue combinations the kernel instantiates (see `epilogue` in conv_igemm_kernel)
+    const bool bn_cell = a.scale && a.shift && a.leaky, plain = !a.scale && !a.leaky;
+    if (!((bn_cell && (a.ups != 2 || !a.res)) || (plain && a.ups != 2))) return hipErrorInvalidValue;
+  }
   int bm, bn;
   select_cfg(a, &bm, &bn);
   static const int ring = getenv("VY_CONV_RING") ? atoi(getenv("VY_CONV_RING")) : 0;
