@@ -292,7 +292,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_kernel(const ConvA
     auto stage2 = [&](int buf, int part) {
 #pragma unroll
       for (int j = 0; j < A_INSTR; ++j)
-        if (part < 0 || (j * DMA_GROUPS) / DMA_TOTAL == part) lds_dma16(a_src[j] + a_koff, lds0 + buf * STAGE + (j * NW + wave) * 1024);
+        if (part < 0 || (j * DMA_GROUPS) / DMA_TOTAL == part)
+          lds_dma16(a_src[j] + a_koff, lds0 + buf * STAGE + (j * NW + wave) * 1024);
 #pragma unroll
       for (int j = 0; j < B_INSTR; ++j) {
         if (!(part < 0 || ((A_INSTR + j) * DMA_GROUPS) / DMA_TOTAL == part)) continue;
@@ -549,7 +550,7 @@ int vy_conv_tiles_m(const ConvArgs& a) {
 
 hipError_t vy_launch_conv_igemm(const ConvArgs& a_in, hipStream_t s) {
   // timing experiments only (results are wrong): VY_DEBUG_CONV bit0 = skip the LDS-DMA of tiles > 0,
-  // bit1 = skip the per-k-step barrier
+  // bit1 = skip the per-k-step barrier (both for schedule 0 only)
   static const int dbg = getenv("VY_DEBUG_CONV") ? atoi(getenv("VY_DEBUG_CONV")) : 0;
   ConvArgs a = a_in;
   a.debug = dbg;
