@@ -301,6 +301,18 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_kernel(const ConvA
         lds_dma16(src, lds0 + buf * STAGE + A_BYTES + (j * NW + wave) * 1024);
       }
     };
+    // one DMA instruction by index (A tile first, then W): SCHED 6 issues one after every MFMA step
+    auto stage_one = [&](int buf, int d) {
+#pragma unroll
+      for (int j = 0; j < A_INSTR; ++j)
+        if (j == d) lds_dma16(a_src[j] + a_koff, lds0 + buf * STAGE + (j * NW + wave) * 1024);
+#pragma unroll
+      for (int j = 0; j < B_INSTR; ++j) {
+        if (A_INSTR + j != d) continue;
+        const float* src = DGRAD ? b_src[j] + b_koff + (n_lastcc ? b_row_last[j] : b_row[j]) : b_src[j] + b_koff;
+        lds_dma16(src, lds0 + buf * STAGE + A_BYTES + (j * NW + wave) * 1024);
+      }
+    };
     auto ktile = [&](int t, auto prefetch) {
       constexpr bool PREFETCH = decltype(prefetch)::value;
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -345,6 +357,19 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_kernel(const ConvA
         // SCHED 1: [step0] DMA [step1 step2] reads(g+1) [step3]
         // SCHED 2: [step0] DMA [step1] reads(g+1) [step2 step3]
         // SCHED 3: [step0 step1] DMA [step2] reads(g+1) [step3]
+        if constexpr (SCHED == 6) {
+          // [step0] DMA [step1] DMA [step2] DMA + reads(g+1) [step3] DMA: never more than one DMA between
+          // two MFMA steps, everything issued within the first ceil(DMA_TOTAL / 4) groups
+#pragma unroll
+          for (int st = 0; st < 4; ++st) {
+            mfma_step(cur, st);
+            __builtin_amdgcn_sched_barrier(0);
+            if (PREFETCH && g * 4 + st < DMA_TOTAL) stage_one(nbuf, g * 4 + st);
+            if (st == 2 && g + 1 < 4) load_group(g + 1, cur ^ 1);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          continue;
+        }
         mfma_step(cur, 0);
         if (SCHED >= 3) mfma_step(cur, 1);
         __builtin_amdgcn_sched_barrier(0);
@@ -508,6 +533,7 @@ static hipError_t launch_cfg(const ConvArgs& a, hipStream_t s) {
   static const int sched = getenv("VY_CONV_SCHED") ? atoi(getenv("VY_CONV_SCHED")) : 3;
   if (sched == 0) return launch_sched<BM, BN, WM, WN, 0>(a, s);
   if (sched == 4) return launch_sched<BM, BN, WM, WN, 4>(a, s);
+  if (sched == 6) return launch_sched<BM, BN, WM, WN, 6>(a, s);
   return launch_sched<BM, BN, WM, WN, 3>(a, s);
 }
 
