@@ -24,11 +24,11 @@
 // order 0,4,1,5,2,6,3,7 per aligned group of 8 — the order the CPU checker uses too, which makes
 // the conv stack bit-reproducible with zero cross-lane traffic.
 //
-// Tiling (MI355X): 4 waves (128 x BN tiles) or 8 waves (256 x 128); k-step 32; per k-step the A and W
+// Tiling (MI355X): 4 waves, tiles 128 x {128, 64, 32} and 64 x 64; k-step 32; per k-step the A and W
 // tiles (128 B per row) are brought in by LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave
 // instruction) into a double buffer; the 16-B chunk index is XOR-swizzled on the SOURCE side with
 // (row>>1)&7 so the ds_read_b128 of 32 different rows at one k-chunk is bank-conflict free.
-// 128x128 tile: 64 KiB of LDS -> 2 blocks / CU, 64 accumulator VGPRs / lane.
+// 128x128 tile: 66 KiB of LDS -> 2 blocks / CU, 64 accumulator VGPRs / lane.
 // dgrad reads W as the [k][n] operand: its LDS tile is 32 k-rows of BN contiguous floats, read with
 // ds_read_b32 (32 consecutive floats per half-wave: conflict-free without a swizzle).
 #include <cstdlib>
@@ -64,7 +64,7 @@ __device__ __forceinline__ void buf_store_f32(float v, __amdgpu_buffer_rsrc_t rs
 }
 #endif
 
-template <int BM, int BN, int WM, int WN, bool DGRAD, int SCHED = 0>
+template <int BM, int BN, int WM, int WN, bool DGRAD>
 // 2nd launch-bounds argument = waves per SIMD the register allocation must allow: two (2 blocks/CU of 4
 // waves, or one 8-wave block).  Without it hipcc let the register count drift past 256 and silently
 // halved the occupancy of some variants.
@@ -175,220 +175,110 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_kernel(const ConvA
   const int cchunks = a.Kc >> 5;
   const int T = a.ntaps * cchunks;
 
-  // LDS-DMA of tile t into buffer buf; `part` selects a quarter of the instructions (or -1: all) so the
-  // issue cost (~100 cycles per instruction) can be spread behind the MFMA groups of the current tile
-  auto stage = [&](int t, int buf, int part) {
-    const int tap = t / cchunks;
-    const int cc = t - tap * cchunks;
-    // tap tables are bit-packed kernel arguments: pure scalar ALU, no memory access in the k-loop
-    const int tdy = (int)((a.pk_dy >> (2 * tap)) & 3u) - 1, tdx = (int)((a.pk_dx >> (2 * tap)) & 3u) - 1;
-    const int tw = (int)((a.pk_w >> (4 * tap)) & 15ull);
-    const long long a_koff = (long long)(tdy * a.a_Wp + tdx) * a.a_cs + cc * 32;
-#pragma unroll
-    for (int j = 0; j < A_INSTR; ++j)
-      if (part < 0 || (j & 3) == part)
-        lds_dma16(a_src[j] + a_koff, lds0 + buf * STAGE + (j * NW + wave) * 1024);
-    if (!DGRAD) {
-      const int b_koff = tw * a.w_cin + cc * 32;
-#pragma unroll
-      for (int j = 0; j < B_INSTR; ++j)
-        if (part < 0 || (j & 3) == part)
-          lds_dma16(b_src[j] + b_koff, lds0 + buf * STAGE + A_BYTES + (j * NW + wave) * 1024);
-    } else {
-#pragma unroll
-      for (int j = 0; j < B_INSTR; ++j) {
-        if (!(part < 0 || (j & 3) == part)) continue;
-        int o = cc * 32 + b_krow[j];
-        o = o < a.w_cout ? o : a.w_cout - 1;  // padded k rows: A is zero there
-        const long long off = ((long long)o * a.w_taps + tw) * a.w_cin;
-        lds_dma16(b_src[j] + off, lds0 + buf * STAGE + A_BYTES + (j * NW + wave) * 1024);
-      }
+  const int lrow = lane & 31;
+  // ---- k-loop.  Wave-uniform tile state (tap, channel chunk -> A / W offsets) is advanced once per tile
+  // with scalar arithmetic; the last tile is peeled (no prefetch); fragments are double-buffered in
+  // registers; sched_barriers pin the order  [MFMA steps 0,1] [a third of the next tile's DMA] [step 2]
+  // [next group's ds_reads] [step 3]  per 8-channel group.
+  int n_tap = 0, n_cc = 0;
+  long long a_koff = 0, b_koff = 0;
+  bool n_lastcc = false;
+  auto advance = [&]() {
+    const int tdy = (int)((a.pk_dy >> (2 * n_tap)) & 3u) - 1, tdx = (int)((a.pk_dx >> (2 * n_tap)) & 3u) - 1;
+    const int tw = (int)((a.pk_w >> (4 * n_tap)) & 15ull);
+    a_koff = (long long)(tdy * a.a_Wp + tdx) * a.a_cs + n_cc * 32;
+    if (!DGRAD)
+      b_koff = tw * a.w_cin + n_cc * 32;
+    else
+      b_koff = ((long long)n_cc * 32 * a.w_taps + tw) * a.w_cin;
+    n_lastcc = (n_cc == cchunks - 1);
+    if (++n_cc == cchunks) {
+      n_cc = 0;
+      ++n_tap;
     }
   };
-
-  const int lrow = lane & 31;
-  if constexpr (SCHED == 0) {
-  stage(0, 0, -1);
-  for (int t = 0; t < T; ++t) {
-    // tile t has landed (own DMA waited, then everyone's via the barrier) and every wave is done
-    // reading the other buffer (it computed tile t-1 before arriving here)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of tile t has landed
-    if (!(a.debug & 2)) __syncthreads();
-    const bool more = (t + 1 < T) && !(a.debug & 1);
+  long long b_row[B_INSTR], b_row_last[B_INSTR];
+#pragma unroll
+  for (int j = 0; j < B_INSTR; ++j) {
+    b_row[j] = (long long)b_krow[j] * a.w_taps * a.w_cin;
+    int o = (cchunks - 1) * 32 + b_krow[j];
+    o = o < a.w_cout ? o : a.w_cout - 1;
+    b_row_last[j] = (long long)(o - (cchunks - 1) * 32) * a.w_taps * a.w_cin;
+  }
+  // DMA instruction idx (A: 0..A_INSTR-1, W: A_INSTR..) goes behind MFMA group idx*3/total: groups 0-2
+  // carry everything, group 3 nothing, so the last DMA has a whole group (>= 16 MFMAs) to land before
+  // the tile-end vmcnt(0)
+  constexpr int DMA_TOTAL = A_INSTR + B_INSTR;
+  constexpr int DMA_GROUPS = 3;
+  auto stage2 = [&](int buf, int part) {
+#pragma unroll
+    for (int j = 0; j < A_INSTR; ++j)
+      if (part < 0 || (j * DMA_GROUPS) / DMA_TOTAL == part)
+        lds_dma16(a_src[j] + a_koff, lds0 + buf * STAGE + (j * NW + wave) * 1024);
+#pragma unroll
+    for (int j = 0; j < B_INSTR; ++j) {
+      if (!(part < 0 || ((A_INSTR + j) * DMA_GROUPS) / DMA_TOTAL == part)) continue;
+      const float* src = DGRAD ? b_src[j] + b_koff + (n_lastcc ? b_row_last[j] : b_row[j]) : b_src[j] + b_koff;
+      lds_dma16(src, lds0 + buf * STAGE + A_BYTES + (j * NW + wave) * 1024);
+    }
+  };
+  auto ktile = [&](int t, auto prefetch) {
+    constexpr bool PREFETCH = decltype(prefetch)::value;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (PREFETCH) advance();
+    const int nbuf = (t + 1) & 1;
     const unsigned char* sA = smem + (t & 1) * STAGE;
     const unsigned char* sB = sA + A_BYTES;
-    // Per 8-k group g: the lower half-wave reads 16-B chunk 2g (channels 8g..8g+3), the upper half
-    // chunk 2g+1 (channels 8g+4..8g+7) — every LDS byte is read once, no cross-lane movement.  MFMA
-    // step j of the group then multiplies channel 8g+j (lanes 0-31, the k0 slot) and 8g+4+j (lanes
-    // 32-63, the k1 slot): within a group of 8 the fma chain visits channels 0,4,1,5,2,6,3,7.  That
-    // IS the summation order of this framework (the CPU checker walks the same order).
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      f32x4 af[TM], bf[TN];
-      float bs[TN][4];
+    f32x4 af[2][TM], bf[2][TN];
+    float bs[2][TN][4];
+    auto load_group = [&](int g, int buf) {
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
         const int row = (wm * TM + i) * 32 + lrow;
-        af[i] = *reinterpret_cast<const f32x4*>(sA + row * 128 + (((2 * g + h) ^ ((row >> 1) & 7)) << 4));
+        af[buf][i] = *reinterpret_cast<const f32x4*>(sA + row * 128 + (((2 * g + h) ^ ((row >> 1) & 7)) << 4));
       }
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         if (!DGRAD) {
           const int row = (wn * TN + j) * 32 + lrow;
-          bf[j] = *reinterpret_cast<const f32x4*>(sB + row * 128 + (((2 * g + h) ^ ((row >> 1) & 7)) << 4));
+          bf[buf][j] = *reinterpret_cast<const f32x4*>(sB + row * 128 + (((2 * g + h) ^ ((row >> 1) & 7)) << 4));
         } else {
           const int col = (wn * TN + j) * 32 + lrow;
           const float* tb = reinterpret_cast<const float*>(sB);
 #pragma unroll
-          for (int st = 0; st < 4; ++st) bs[j][st] = tb[(g * 8 + 4 * h + st) * BN + col];
+          for (int st = 0; st < 4; ++st) bs[buf][j][st] = tb[(g * 8 + 4 * h + st) * BN + col];
         }
       }
+    };
+    auto mfma_step = [&](int buf, int st) {
 #pragma unroll
-      for (int st = 0; st < 4; ++st) {
+      for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[buf][i][st], DGRAD ? bs[buf][j][st] : bf[buf][j][st],
+                                                           acc[i][j], 0, 0, 0);
+    };
+    load_group(0, 0);
 #pragma unroll
-          for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][st], DGRAD ? bs[j][st] : bf[j][st], acc[i][j], 0, 0, 0);
-        // a quarter of the next tile's DMA, issued while this group's MFMAs occupy the matrix pipe
-        if (st == 0 && more) stage(t + 1, (t + 1) & 1, g);
-      }
+    for (int g = 0; g < 4; ++g) {
+      const int cur = g & 1;
+      mfma_step(cur, 0);
+      mfma_step(cur, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      if (PREFETCH) stage2(nbuf, g);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_step(cur, 2);
+      __builtin_amdgcn_sched_barrier(0);
+      if (g + 1 < 4) load_group(g + 1, cur ^ 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_step(cur, 3);
     }
-  }
-
-  } else {
-    // ---- experimental schedules (VY_CONV_SCHED): wave-uniform tile state advanced once per tile with
-    // scalar adds, peeled last tile, explicit placement of the DMA quarter and of the next group's reads
-    int n_tap = 0, n_cc = 0;
-    long long a_koff = 0, b_koff = 0;
-    bool n_lastcc = false;
-    auto advance = [&]() {
-      const int tdy = (int)((a.pk_dy >> (2 * n_tap)) & 3u) - 1, tdx = (int)((a.pk_dx >> (2 * n_tap)) & 3u) - 1;
-      const int tw = (int)((a.pk_w >> (4 * n_tap)) & 15ull);
-      a_koff = (long long)(tdy * a.a_Wp + tdx) * a.a_cs + n_cc * 32;
-      if (!DGRAD)
-        b_koff = tw * a.w_cin + n_cc * 32;
-      else
-        b_koff = ((long long)n_cc * 32 * a.w_taps + tw) * a.w_cin;
-      n_lastcc = (n_cc == cchunks - 1);
-      if (++n_cc == cchunks) {
-        n_cc = 0;
-        ++n_tap;
-      }
-    };
-    long long b_row[B_INSTR], b_row_last[B_INSTR];
-#pragma unroll
-    for (int j = 0; j < B_INSTR; ++j) {
-      b_row[j] = (long long)b_krow[j] * a.w_taps * a.w_cin;
-      int o = (cchunks - 1) * 32 + b_krow[j];
-      o = o < a.w_cout ? o : a.w_cout - 1;
-      b_row_last[j] = (long long)(o - (cchunks - 1) * 32) * a.w_taps * a.w_cin;
-    }
-    // DMA instruction idx (A: 0..A_INSTR-1, W: A_INSTR..) goes behind MFMA group idx*3/total: groups 0-2
-    // carry everything, group 3 nothing, so the last DMA has a whole group (>= 16 MFMAs) to land before
-    // the tile-end vmcnt(0)
-    constexpr int DMA_TOTAL = A_INSTR + B_INSTR;
-    constexpr int DMA_GROUPS = (SCHED == 4) ? 2 : 3;
-    auto stage2 = [&](int buf, int part) {
-#pragma unroll
-      for (int j = 0; j < A_INSTR; ++j)
-        if (part < 0 || (j * DMA_GROUPS) / DMA_TOTAL == part)
-          lds_dma16(a_src[j] + a_koff, lds0 + buf * STAGE + (j * NW + wave) * 1024);
-#pragma unroll
-      for (int j = 0; j < B_INSTR; ++j) {
-        if (!(part < 0 || ((A_INSTR + j) * DMA_GROUPS) / DMA_TOTAL == part)) continue;
-        const float* src = DGRAD ? b_src[j] + b_koff + (n_lastcc ? b_row_last[j] : b_row[j]) : b_src[j] + b_koff;
-        lds_dma16(src, lds0 + buf * STAGE + A_BYTES + (j * NW + wave) * 1024);
-      }
-    };
-    // one DMA instruction by index (A tile first, then W): SCHED 6 issues one after every MFMA step
-    auto stage_one = [&](int buf, int d) {
-#pragma unroll
-      for (int j = 0; j < A_INSTR; ++j)
-        if (j == d) lds_dma16(a_src[j] + a_koff, lds0 + buf * STAGE + (j * NW + wave) * 1024);
-#pragma unroll
-      for (int j = 0; j < B_INSTR; ++j) {
-        if (A_INSTR + j != d) continue;
-        const float* src = DGRAD ? b_src[j] + b_koff + (n_lastcc ? b_row_last[j] : b_row[j]) : b_src[j] + b_koff;
-        lds_dma16(src, lds0 + buf * STAGE + A_BYTES + (j * NW + wave) * 1024);
-      }
-    };
-    auto ktile = [&](int t, auto prefetch) {
-      constexpr bool PREFETCH = decltype(prefetch)::value;
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      if (PREFETCH) advance();
-      const int nbuf = (t + 1) & 1;
-      const unsigned char* sA = smem + (t & 1) * STAGE;
-      const unsigned char* sB = sA + A_BYTES;
-      f32x4 af[2][TM], bf[2][TN];
-      float bs[2][TN][4];
-      auto load_group = [&](int g, int buf) {
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-          const int row = (wm * TM + i) * 32 + lrow;
-          af[buf][i] = *reinterpret_cast<const f32x4*>(sA + row * 128 + (((2 * g + h) ^ ((row >> 1) & 7)) << 4));
-        }
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          if (!DGRAD) {
-            const int row = (wn * TN + j) * 32 + lrow;
-            bf[buf][j] = *reinterpret_cast<const f32x4*>(sB + row * 128 + (((2 * g + h) ^ ((row >> 1) & 7)) << 4));
-          } else {
-            const int col = (wn * TN + j) * 32 + lrow;
-            const float* tb = reinterpret_cast<const float*>(sB);
-#pragma unroll
-            for (int st = 0; st < 4; ++st) bs[buf][j][st] = tb[(g * 8 + 4 * h + st) * BN + col];
-          }
-        }
-      };
-      auto mfma_step = [&](int buf, int st) {
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[buf][i][st], DGRAD ? bs[buf][j][st] : bf[buf][j][st],
-                                                             acc[i][j], 0, 0, 0);
-      };
-      load_group(0, 0);
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int cur = g & 1;
-        // SCHED 1: [step0] DMA [step1 step2] reads(g+1) [step3]
-        // SCHED 2: [step0] DMA [step1] reads(g+1) [step2 step3]
-        // SCHED 3: [step0 step1] DMA [step2] reads(g+1) [step3]
-        if constexpr (SCHED == 6) {
-          // [step0] DMA [step1] DMA [step2] DMA + reads(g+1) [step3] DMA: never more than one DMA between
-          // two MFMA steps, everything issued within the first ceil(DMA_TOTAL / 4) groups
-#pragma unroll
-          for (int st = 0; st < 4; ++st) {
-            mfma_step(cur, st);
-            __builtin_amdgcn_sched_barrier(0);
-            if (PREFETCH && g * 4 + st < DMA_TOTAL) stage_one(nbuf, g * 4 + st);
-            if (st == 2 && g + 1 < 4) load_group(g + 1, cur ^ 1);
-            __builtin_amdgcn_sched_barrier(0);
-          }
-          continue;
-        }
-        mfma_step(cur, 0);
-        if (SCHED >= 3) mfma_step(cur, 1);
-        __builtin_amdgcn_sched_barrier(0);
-        if (PREFETCH) stage2(nbuf, g);
-        __builtin_amdgcn_sched_barrier(0);
-        if (SCHED < 3) mfma_step(cur, 1);
-        if (SCHED != 2) mfma_step(cur, 2);
-        __builtin_amdgcn_sched_barrier(0);
-        if (g + 1 < 4) load_group(g + 1, cur ^ 1);
-        __builtin_amdgcn_sched_barrier(0);
-        if (SCHED == 2) mfma_step(cur, 2);
-        mfma_step(cur, 3);
-      }
-    };
-    advance();
-    stage2(0, -1);
-    for (int t = 0; t + 1 < T; ++t) ktile(t, std::true_type{});
-    ktile(T - 1, std::false_type{});
-  }
+  };
+  advance();
+  stage2(0, -1);
+  for (int t = 0; t + 1 < T; ++t) ktile(t, std::true_type{});
+  ktile(T - 1, std::false_type{});
 
   // epilogue: affine (folded BN or bias) -> leaky -> + addend -> store (x1 or x2-replicated), through
   // buffer descriptors based at the tile's first pixel and column (see the row tables above)
@@ -514,27 +404,16 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_kernel(const ConvA
 #endif  // __HIP_DEVICE_COMPILE__
 }
 
-template <int BM, int BN, int WM, int WN, int SCHED>
-static hipError_t launch_sched(const ConvArgs& a, hipStream_t s) {
-  const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + BN - 1) / BN;
-  if (a.dgrad)
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, true, SCHED>), dim3(tiles_m * tiles_n), dim3(WM * WN * 64), 0,
-                       s, a, tiles_n);
-  else
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, false, SCHED>), dim3(tiles_m * tiles_n), dim3(WM * WN * 64), 0,
-                       s, a, tiles_n);
-  return hipGetLastError();
-}
-
-// k-loop schedule: 3 = [MFMA steps 0,1] DMA third [step 2] next group's ds_reads [step 3], the measured
-// best (VY_CONV_SCHED selects the others for experiments: 0 = scheduler's choice, 4 = DMA in two halves)
 template <int BM, int BN, int WM, int WN>
 static hipError_t launch_cfg(const ConvArgs& a, hipStream_t s) {
-  static const int sched = getenv("VY_CONV_SCHED") ? atoi(getenv("VY_CONV_SCHED")) : 3;
-  if (sched == 0) return launch_sched<BM, BN, WM, WN, 0>(a, s);
-  if (sched == 4) return launch_sched<BM, BN, WM, WN, 4>(a, s);
-  if (sched == 6) return launch_sched<BM, BN, WM, WN, 6>(a, s);
-  return launch_sched<BM, BN, WM, WN, 3>(a, s);
+  const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + BN - 1) / BN;
+  if (a.dgrad)
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, true>), dim3(tiles_m * tiles_n), dim3(WM * WN * 64), 0, s, a,
+                       tiles_n);
+  else
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, false>), dim3(tiles_m * tiles_n), dim3(WM * WN * 64), 0, s, a,
+                       tiles_n);
+  return hipGetLastError();
 }
 
 // Tile choice: the 128x128 tile has the best arithmetic intensity, but a launch needs >= ~2 blocks
@@ -548,13 +427,7 @@ static void select_cfg(const ConvArgs& a, int* bm, int* bn) {
     return;
   }
   const long long want = 1024;
-  // measured slower than 128x128 at 2 blocks/CU (110 vs 120 TF on the 76x76 layers: its two waves per
-  // SIMD share one barrier and run in lockstep); kept as an experiment switch
-  static const int big = getenv("VY_CONV_BIG") ? atoi(getenv("VY_CONV_BIG")) : 0;
-  if (big && a.N > 64 && blocks(256, 128) >= 2 * want) {
-    *bm = 256;  // 512 threads, one block per CU: 25 % fewer LDS-DMA instructions per FLOP
-    *bn = 128;
-  } else if (a.N > 64 && blocks(128, 128) >= want) {
+  if (a.N > 64 && blocks(128, 128) >= want) {
     *bm = 128;
     *bn = 128;
   } else if (blocks(128, 64) >= want || a.M <= 64) {
@@ -575,11 +448,7 @@ int vy_conv_tiles_m(const ConvArgs& a) {
 }
 
 hipError_t vy_launch_conv_igemm(const ConvArgs& a_in, hipStream_t s) {
-  // timing experiments only (results are wrong): VY_DEBUG_CONV bit0 = skip the LDS-DMA of tiles > 0,
-  // bit1 = skip the per-k-step barrier (both for schedule 0 only)
-  static const int dbg = getenv("VY_DEBUG_CONV") ? atoi(getenv("VY_DEBUG_CONV")) : 0;
   ConvArgs a = a_in;
-  a.debug = dbg;
   a.pk_dy = a.pk_dx = 0;
   a.pk_w = 0;
   for (int t = 0; t < a.ntaps; ++t) {
@@ -596,11 +465,8 @@ hipError_t vy_launch_conv_igemm(const ConvArgs& a_in, hipStream_t s) {
   }
   int bm, bn;
   select_cfg(a, &bm, &bn);
-  static const int ring = getenv("VY_CONV_RING") ? atoi(getenv("VY_CONV_RING")) : 0;
-  if (ring && !a.dgrad && bn >= 64 && bm <= 128) return vy_launch_conv_ring(a, bm, bn, s);
   if (bn == 32) return launch_cfg<128, 32, 4, 1>(a, s);
   if (bm == 128 && bn == 64) return launch_cfg<128, 64, 2, 2>(a, s);
   if (bm == 64) return launch_cfg<64, 64, 2, 2>(a, s);
-  if (bm == 256) return launch_cfg<256, 128, 4, 2>(a, s);
   return launch_cfg<128, 128, 2, 2>(a, s);
 }

@@ -33,7 +33,6 @@ struct ConvArgs {
   int r_cs, r_co;
   int leaky;            // LeakyReLU(0.1) after the affine
   int dgrad;            // 0: W is the [n][k] operand (forward); 1: W is the [k][n] operand (dgrad)
-  int debug;            // timing experiments (VY_DEBUG_CONV); 0 in production
   unsigned pk_dy, pk_dx;        // filled by the launcher: tap tables packed 2 bits / tap (value + 1)
   unsigned long long pk_w;      // 4 bits / tap
 };
@@ -41,7 +40,6 @@ struct ConvArgs {
 // 3x3/1x1 implicit-GEMM convolution on v_mfma_f32_32x32x2_f32.
 hipError_t vy_launch_conv_igemm(const ConvArgs& a, hipStream_t s);
 int vy_conv_tiles_m(const ConvArgs& a);
-hipError_t vy_launch_conv_ring(const ConvArgs& a, int bm, int bn, hipStream_t s);  // conv_ring.hip
 void vy_conv_cfg(const ConvArgs& a, int* bm, int* bn);  // block tile the launch will use
 
 // stem: 3x3 stride-1 conv from the caller's NCHW image (Cin = 3) into a plane, fused affine+leaky.
