@@ -355,131 +355,73 @@ hipError_t vy_launch_colsum(const float* plane, int B, int H, int W, int cs, int
 }
 
 // ------------------------------------------------------------------------------------------------
-// Stem in training: raw conv output + per-block channel sums.  Same thread mapping as stem_kernel.
-int vy_stem_blocks(int B, int H, int W) { return (int)(((long long)B * H * W + 255) / 256); }
+// (the stem's training forward, raw conv + per-block channel sums, is stem_kernel<true> in misc_kernels.hip)
 
-__global__ __launch_bounds__(256) void stem_raw_kernel(const StemArgs a, double* __restrict__ partials) {
-  __shared__ float sw[32 * 27];
-  __shared__ double red[2][4][32];
-  for (int i = threadIdx.x; i < 32 * 27; i += 256) sw[i] = a.w[i];
-  __syncthreads();
-  const long long npix = (long long)a.B * a.H * a.W;
-  const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
-  const bool live = p < npix;
-  float in[27];
-  float accs[32];
-  if (live) {
-    const int x = (int)(p % a.W);
-    const long long t = p / a.W;
-    const int y = (int)(t % a.H);
-    const int b = (int)(t / a.H);
-    const float* xb = a.x + (long long)b * 3 * a.H * a.W;
-#pragma unroll
-    for (int kh = 0; kh < 3; ++kh)
-#pragma unroll
-      for (int kw = 0; kw < 3; ++kw) {
-        const int iy = y + kh - 1, ix = x + kw - 1;
-        const bool ok = iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
-#pragma unroll
-        for (int c = 0; c < 3; ++c) in[(kh * 3 + kw) * 3 + c] = ok ? xb[((long long)c * a.H + iy) * a.W + ix] : 0.0f;
-      }
-    float* o = a.out + ((long long)(b * (a.H + 2) + y + 1) * (a.W + 2) + x + 1) * a.out_cs + a.out_co;
-#pragma unroll
-    for (int o4 = 0; o4 < 32; o4 += 4) {
-      f32x4 r;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        float acc = 0.0f;
-#pragma unroll
-        for (int k = 0; k < 27; ++k) acc = fmaf(in[k], sw[(o4 + q) * 27 + k], acc);
-        r[q] = acc;
-        accs[o4 + q] = acc;
-      }
-      *reinterpret_cast<f32x4*>(o + o4) = r;
-    }
-  } else {
-#pragma unroll
-    for (int i = 0; i < 32; ++i) accs[i] = 0.0f;
-  }
-  // wave reduction of 32 channel sums (and squares), then across the 4 waves through LDS
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-  for (int c = 0; c < 32; ++c) {
-    double s1 = (double)accs[c], s2 = (double)accs[c] * (double)accs[c];
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-      s1 += __shfl_xor(s1, off);
-      s2 += __shfl_xor(s2, off);
-    }
-    if (lane == 0) {
-      red[0][wave][c] = s1;
-      red[1][wave][c] = s2;
-    }
-  }
-  __syncthreads();
-  if (threadIdx.x < 64) {
-    const int which = threadIdx.x >> 5, c = threadIdx.x & 31;
-    const double s = (red[which][0][c] + red[which][1][c]) + (red[which][2][c] + red[which][3][c]);
-    partials[(long long)blockIdx.x * 64 + which * 32 + c] = s;
-  }
+// Stem weight gradient: dW[o][k] = sum_p dz[p][o] * patch[p][k], k = (kh,kw,cin) (27) — a 32 x 27 output
+// reduced over B*H*W pixels (2.8 M at 416x416 batch 16).  On the matrix core: D[i=o][j=k] += A[i][p] B[p][j],
+// two pixels per v_mfma_f32_32x32x2_f32.  Both operands come straight from global memory: lane (o, h) reads
+// dz[p+h][o] (a pixel's 32 channels = one 128-B line per half-wave) and lane (k, h) gathers the image value
+// of tap k at pixel p+h from the NCHW frame (L1/L2 resident: every input value is used by 27 lanes).
+// One wave = kStemWgradPix pixels into one 32x32 accumulator; the four waves of a block are summed through
+// LDS in wave order; partials [blocks][32*27] go to the ordered second-stage reduce.
+constexpr int kStemWgradPix = 512;
+int vy_stem_wgrad_blocks(int B, int H, int W) {
+  return (int)(((long long)B * H * W + 4 * kStemWgradPix - 1) / (4 * kStemWgradPix));
 }
 
-hipError_t vy_launch_stem_raw(const StemArgs& a, double* partials, hipStream_t s) {
-  if (a.Cout != 32 || (a.out_cs & 3) || (a.out_co & 3)) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(stem_raw_kernel, dim3(vy_stem_blocks(a.B, a.H, a.W)), dim3(256), 0, s, a, partials);
-  return hipGetLastError();
-}
-
-// Stem weight gradient: dW[o][k] = sum_p dz[p][o] * patch[p][k], k = (kh,kw,cin) (27).
-// One block = 256 pixels: thread t owns pixel t's patch (27) staged in LDS with its dz row (32);
-// then thread (o, kgroup) accumulates over the 256 pixels.  partials [blocks][32*27].
-int vy_stem_wgrad_blocks(int B, int H, int W) { return (int)(((long long)B * H * W + 255) / 256); }
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
 
 __global__ __launch_bounds__(256) void stem_wgrad_kernel(const StemWgradArgs a) {
-  __shared__ float sp[256][28];   // patch, padded
-  __shared__ float sz[256][33];   // dz row, padded
+#if defined(__HIP_DEVICE_COMPILE__)
+  __shared__ float red[4][32][33];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lrow = lane & 31, h = lane >> 5;
   const long long npix = (long long)a.B * a.H * a.W;
-  const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
-  const int t = threadIdx.x;
-  if (p < npix) {
-    const int x = (int)(p % a.W);
-    const long long tt = p / a.W;
-    const int y = (int)(tt % a.H);
-    const int b = (int)(tt / a.H);
-    const float* xb = a.x + (long long)b * 3 * a.H * a.W;
+  const long long p0 = ((long long)blockIdx.x * 4 + wave) * kStemWgradPix;
+  // this lane's tap (B operand column k = lrow): k = (kh*3 + kw)*3 + c
+  const bool kvalid = lrow < 27;
+  const int kh = lrow / 9, kw = (lrow / 3) % 3, kc = lrow % 3;
+  const int dy = kh - 1, dx = kw - 1;
+  // pixel of this lane at step 0: p0 + h; advanced by 2 per step
+  long long p = p0 + h;
+  int x = (int)(p % a.W);
+  long long t = p / a.W;
+  int y = (int)(t % a.H), b = (int)(t / a.H);
+  f32x16_t acc;
 #pragma unroll
-    for (int kh = 0; kh < 3; ++kh)
+  for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+  constexpr int U = 8;
+  for (int s0 = 0; s0 < kStemWgradPix / 2; s0 += U) {
+    float av[U], bv[U];
 #pragma unroll
-      for (int kw = 0; kw < 3; ++kw) {
-        const int iy = y + kh - 1, ix = x + kw - 1;
-        const bool ok = iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
-#pragma unroll
-        for (int c = 0; c < 3; ++c) sp[t][(kh * 3 + kw) * 3 + c] = ok ? xb[((long long)c * a.H + iy) * a.W + ix] : 0.0f;
+    for (int u = 0; u < U; ++u) {
+      const bool ok = p < npix;
+      const int iy = y + dy, ix = x + dx;
+      const bool inb = ok && kvalid && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+      av[u] = ok ? a.dz[((long long)(b * (a.H + 2) + y + 1) * (a.W + 2) + x + 1) * 32 + lrow] : 0.0f;
+      bv[u] = inb ? a.x[((long long)(b * 3 + kc) * a.H + iy) * a.W + ix] : 0.0f;
+      p += 2;
+      x += 2;
+      if (x >= a.W) {  // W >= 32: at most one wrap per step
+        x -= a.W;
+        if (++y == a.H) {
+          y = 0;
+          ++b;
+        }
       }
-    const float* dzp = a.dz + ((long long)(b * (a.H + 2) + y + 1) * (a.W + 2) + x + 1) * 32;
-#pragma unroll
-    for (int o = 0; o < 32; ++o) sz[t][o] = dzp[o];
-  } else {
-    for (int k = 0; k < 27; ++k) sp[t][k] = 0.0f;
-    for (int o = 0; o < 32; ++o) sz[t][o] = 0.0f;
-  }
-  __syncthreads();
-  // 864 outputs over 256 threads: thread handles (o = t & 31, k = (t >> 5) + 8*j), j = 0..3 (k < 27)
-  const int o = t & 31, k0 = t >> 5;
-  float acc[4] = {0, 0, 0, 0};
-  for (int q = 0; q < 256; ++q) {
-    const float d = sz[q][o];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int k = k0 + 8 * j;
-      if (k < 27) acc[j] = fmaf(d, sp[q][k], acc[j]);
     }
-  }
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int k = k0 + 8 * j;
-    if (k < 27) a.partials[(long long)blockIdx.x * 864 + o * 27 + k] = acc[j];
+    for (int u = 0; u < U; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u], acc, 0, 0, 0);
   }
+  // acc[r] = D[o = (r&3) + 8*(r>>2) + 4*h][k = lrow]
+#pragma unroll
+  for (int r = 0; r < 16; ++r) red[wave][(r & 3) + 8 * (r >> 2) + 4 * h][lrow] = acc[r];
+  __syncthreads();
+  for (int e = threadIdx.x; e < 32 * 27; e += 256) {
+    const int o = e / 27, k = e - o * 27;
+    a.partials[(long long)blockIdx.x * 864 + e] = ((red[0][o][k] + red[1][o][k]) + red[2][o][k]) + red[3][o][k];
+  }
+#endif
 }
 
 hipError_t vy_launch_stem_wgrad(const StemWgradArgs& a, hipStream_t s) {
