@@ -111,6 +111,28 @@ def test_nms_settings_and_30_classes():
         np.testing.assert_allclose(scores, r[1], rtol=0, atol=TOL)
 
 
+@pytest.mark.parametrize("ncls,batch,size", [(1, 3, 64), (80, 2, 96), (3, 5, 128)])
+def test_class_counts_and_odd_batches(ncls, batch, size):
+    """1 class (18 prediction channels), 80 classes (255, COCO) and odd batch sizes: head tensors,
+    kept-row indices, ids, scores and boxes against the oracle."""
+    from videoyolo_amd import init
+    from oracle import yolo3_oracle as O
+    classes = ["c%d" % i for i in range(ncls)]
+    params = init.synthetic_params(O.param_shapes(ncls), seed=17 + ncls)
+    x = frames(batch, size, seed=ncls)
+    net = _net(classes, params)
+    ids, scores, bboxes, keep = [t.cpu().numpy() for t in net(x, return_index=True)]
+    orc = _oracle(params, ncls)
+    r = orc(x)
+    assert np.array_equal(keep, r[3]) and np.array_equal(ids, r[0])
+    np.testing.assert_allclose(scores, r[1], rtol=0, atol=TOL)
+    fin = np.isfinite(r[2])
+    np.testing.assert_allclose(bboxes[fin], r[2][fin], rtol=0, atol=TOL)
+    heads = orc.raw_heads(x)
+    for i in range(3):
+        assert np.array_equal(net.read_head(i).cpu().numpy(), heads[i])
+
+
 def test_ties_and_empty():
     """Degenerate inputs: all-zero weights give every candidate the SAME score (0.25): the order
     must fall back to the reference row index; a very negative objectness bias leaves no valid

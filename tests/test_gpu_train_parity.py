@@ -29,7 +29,9 @@ def _net(C, params):
     return net
 
 
-@pytest.mark.parametrize("C,B,S", [(4, 2, 64), (20, 2, 96)])
+# (1, 1, 64): a single class and a single frame (prediction planes 18 -> 32 channels, batch statistics over one
+# image); (80, 1, 96): COCO-sized heads (255 -> 256 channels)
+@pytest.mark.parametrize("C,B,S", [(4, 2, 64), (20, 2, 96), (1, 1, 64), (80, 1, 96)])
 def test_train_step_matches_oracle(C, B, S):
     import videoyolo_amd as vy
     from videoyolo_amd import autograd
@@ -72,7 +74,9 @@ def test_train_step_matches_oracle(C, B, S):
     for name in ("stages.0.0.0.weight", "stages.1.4.body.1.0.weight", "yolo_blocks.1.tip.1.gamma",
                  "yolo_outputs.2.prediction.bias", "transitions.0.0.weight"):
         got = net.collect_params()[name].data()
-        np.testing.assert_allclose(got, p_ref[name], rtol=0, atol=2e-6)
+        # the gradient bar above (2e-3 of the tensor's max) carried through lr / batch, plus fp32 rounding of w
+        atol = 2e-6 + 2e-3 * 1e-3 * float(np.abs(ref_grads[name]).max()) / B
+        np.testing.assert_allclose(got, p_ref[name], rtol=0, atol=atol)
         assert np.abs(got - params[name]).max() > 0
 
 
