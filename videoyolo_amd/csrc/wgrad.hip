@@ -17,6 +17,7 @@
 #include "kernels.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 
@@ -70,40 +71,46 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a, const 
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-  // Each lane stages the same NJ pixel rows of both tiles every k-step (row = 2*(j*4+wave) + h); their
-  // (b, oy, ox) are carried incrementally (+KP pixels per k-step) instead of being re-derived by
-  // integer division each time.
-  int pb[NJ], py[NJ], px[NJ];
+  // Each lane stages the same NJ pixel rows of both tiles every k-step (row = 2*(j*4+wave) + h).  Their
+  // source pointers are carried incrementally: +KP pixels per k-step, plus constant skips over the zero
+  // border when the pixel index wraps to the next image row / the next image — no integer division and
+  // no 64-bit multiplies inside the k-loop.
+  int py[NJ], px[NJ];
+  const float* zp[NJ];
+  const float* ap[NJ];
 #pragma unroll
   for (int j = 0; j < NJ; ++j) {
     const int p = p_begin + 2 * (j * 4 + wave) + h;
     px[j] = p % a.Wo;
     const int tt = p / a.Wo;
     py[j] = tt % a.Ho;
-    pb[j] = tt / a.Ho;
+    const int b = tt / a.Ho;
+    zp[j] = a.dz + ((long long)(b * Hzp + py[j] + 1) * Wzp + px[j] + 1) * a.z_cs + ao;
+    ap[j] = a.a + ((long long)(b * a.a_Hp + py[j] * a.stride + 1 + dy) * a.a_Wp + px[j] * a.stride + 1 + dx) * a.a_cs +
+            a.a_co + cin;
   }
+  const long long z_step = (long long)KP * a.z_cs, a_step = (long long)KP * a.stride * a.a_cs;
+  const long long z_row = 2LL * a.z_cs, a_row = (long long)(a.a_Wp - a.Wo) * a.stride * a.a_cs;
+  const long long z_img = 2LL * Wzp * a.z_cs, a_img = (long long)(a.a_Hp - a.Ho * a.stride) * a.a_Wp * a.a_cs;
   const unsigned lds0 = (unsigned)(unsigned long long)LDS_PTR(smem);
   // one quarter (instruction j) of the LDS-DMA of tile t into buffer buf
   auto stage = [&](int t, int buf, int j) {
     const int q = j * 4 + wave;
-    const int p = p_begin + t * KP + 2 * q + h;
-    const float* pa = a.zero;
-    const float* pb_ = a.zero;
-    if (p < p_end) {
-      if (a_ok) pa = a.dz + ((long long)(pb[j] * Hzp + py[j] + 1) * Wzp + px[j] + 1) * a.z_cs + ao;
-      if (b_ok)
-        pb_ = a.a + ((long long)(pb[j] * a.a_Hp + py[j] * a.stride + 1 + dy) * a.a_Wp + px[j] * a.stride + 1 + dx) * a.a_cs +
-              a.a_co + cin;
-    }
-    lds_dma16(pa, lds0 + buf * STAGE + q * 1024);
-    lds_dma16(pb_, lds0 + buf * STAGE + TILE + q * 1024);
+    const bool live = p_begin + t * KP + 2 * q + h < p_end;
+    lds_dma16(live && a_ok ? zp[j] : a.zero, lds0 + buf * STAGE + q * 1024);
+    lds_dma16(live && b_ok ? ap[j] : a.zero, lds0 + buf * STAGE + TILE + q * 1024);
     // advance this row by KP pixels for the next tile
     px[j] += KP;
+    zp[j] += z_step;
+    ap[j] += a_step;
     while (px[j] >= a.Wo) {
       px[j] -= a.Wo;
+      zp[j] += z_row;
+      ap[j] += a_row;
       if (++py[j] == a.Ho) {
         py[j] = 0;
-        ++pb[j];
+        zp[j] += z_img;
+        ap[j] += a_img;
       }
     }
   };
@@ -120,14 +127,14 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a, const 
     const float* tB = tA + KP * 128;
 #pragma unroll
     for (int g = 0; g < NJ; ++g) {
-      float av[4][2], bv[4][2];
+      // one ds_read_b64 per operand and pixel pair: lane lrow gets rows / columns 2*lrow and 2*lrow+1 of the
+      // wave's 64, so MFMA tile m of an operand covers the interleaved set {2*l + m} (undone in the epilogue)
+      f32x2 av[4], bv[4];
 #pragma unroll
       for (int s4 = 0; s4 < 4; ++s4) {
         const int krow = (2 * (g * 4 + s4) + h) * 128;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) av[s4][i] = tA[krow + (wm * 2 + i) * 32 + lrow];
-#pragma unroll
-        for (int j = 0; j < 2; ++j) bv[s4][j] = tB[krow + (wn * 2 + j) * 32 + lrow];
+        av[s4] = *reinterpret_cast<const f32x2*>(tA + krow + wm * 64 + 2 * lrow);
+        bv[s4] = *reinterpret_cast<const f32x2*>(tB + krow + wn * 64 + 2 * lrow);
       }
 #pragma unroll
       for (int s4 = 0; s4 < 4; ++s4) {
@@ -142,17 +149,20 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a, const 
     }
   }
 
+  // acc[i][j][r] = D[o = o0 + wm*64 + 2*row(r,h) + i][n = n0 + wn*64 + 2*lrow + j]: the two column tiles of
+  // a lane are adjacent in memory -> 8-B stores, 256 B contiguous per half-wave
   float* slab = a.slabs + (long long)split * a.Cout * Ntot;
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int n = n0 + (wn * 2 + j) * 32 + lrow;
-    if (n >= Ntot) continue;
+  const int n = n0 + wn * 64 + 2 * lrow;  // even; Ntot is a multiple of 32
+  if (n < Ntot) {
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int o = o0 + (wm * 2 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (o < a.Cout) slab[(long long)o * Ntot + n] = acc[i][j][r];
+        const int o = o0 + wm * 64 + 2 * ((r & 3) + 8 * (r >> 2) + 4 * h) + i;
+        if (o < a.Cout) {
+          f32x2 v = {acc[i][0][r], acc[i][1][r]};
+          *reinterpret_cast<f32x2*>(slab + (long long)o * Ntot + n) = v;
+        }
       }
   }
 #endif
