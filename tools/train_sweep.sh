@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tools/train_sweep.sh VAR v1 v2 ...   (training bench per value of an env switch)
+# usage: tools/train_sweep.sh VAR v1 v2 ...   (training bench per value of an env switch, e.g. VY_TRAIN_SIDE_STREAM 0 1)
 var=$1; shift
 for v in "$@"; do
   env $var=$v python bench.py --mode train --steps 8 --warmup 3 > /tmp/o.json 2>/dev/null

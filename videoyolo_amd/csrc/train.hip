@@ -80,8 +80,7 @@ constexpr int kBwdChunk = 64;  // pixels per partial-sum block of the BN-backwar
 // BN-backward partial sums: 64 pixels per block on the small maps (enough blocks to fill the chip), more
 // on the large ones so that the ordered second stage stays at <= ~1024 rows
 inline int bwd_chunk(long long npix) {
-  static const int adaptive = getenv("VY_BWD_CHUNK_ADAPT") ? atoi(getenv("VY_BWD_CHUNK_ADAPT")) : 1;
-  if (!adaptive || npix <= 64 * 1024) return kBwdChunk;
+  if (npix <= 64 * 1024) return kBwdChunk;
   return (int)(((npix / 1024) + 63) / 64 * 64);
 }
 
@@ -147,36 +146,15 @@ size_t train_plan(vy_net* net, int b, int h, int w, bool commit) {
     if (!c.is_stem) {
       const int Ntot = c.k * c.k * c.cin;
       const int tiles = ((c.cout + 127) / 128) * ((Ntot + 127) / 128);
-      // Split-K so that the launch fills whole rounds of the 512 resident blocks (2 per CU): the blocks
-      // of one launch are equally long, so 1026 blocks cost three rounds where 1008 cost two.  Take the
-      // fewest rounds whose fill is within 4 % of the best (fewer splits = less slab traffic); a split
-      // is at least 128 pixels (4 k-steps).
-      static const int max_rounds = getenv("VY_WGRAD_ROUNDS") ? atoi(getenv("VY_WGRAD_ROUNDS")) : 0;
-      long long sp = 1, k = ((M + 31) / 32) * 32;
-      double best = -1.0;
-      if (max_rounds == 0) {  // previous heuristic: >= 1024 blocks
-        sp = (1024 + tiles - 1) / tiles;
-        const long long maxsp = (M + 255) / 256;
-        if (sp > maxsp) sp = maxsp;
-        if (sp < 1) sp = 1;
-        k = ((M + sp - 1) / sp + 31) / 32 * 32;
-        sp = (M + k - 1) / k;
-      }
-      for (int r = 1; r <= max_rounds; ++r) {
-        long long s = (512LL * r) / tiles;
-        const long long maxsp = (M + 127) / 128;
-        if (s > maxsp) s = maxsp;
-        if (s < 1) s = 1;
-        const long long k2 = ((M + s - 1) / s + 31) / 32 * 32;
-        const long long s2 = (M + k2 - 1) / k2;
-        const long long blocks = tiles * s2;
-        const double fill = (double)blocks / (double)(((blocks + 511) / 512) * 512);
-        if (fill > best + 0.04) {
-          best = fill;
-          sp = s2;
-          k = k2;
-        }
-      }
+      // Split-K over the pixels so that the launch has >= ~1024 blocks (2 rounds of the 512 resident ones):
+      // the weight gradients run beside the dgrad / BatchNorm chain, where many short blocks fill the gaps
+      // better than a launch sized to whole rounds (measured: 404 vs 401 frames/s); a split is >= 256 pixels
+      long long sp = (1024 + tiles - 1) / tiles;
+      const long long maxsp = (M + 255) / 256;
+      if (sp > maxsp) sp = maxsp;
+      if (sp < 1) sp = 1;
+      const long long k = ((M + sp - 1) / sp + 31) / 32 * 32;
+      sp = (M + k - 1) / k;
       splits[i] = (int)sp;
       kps[i] = (int)k;
       const size_t sl = (size_t)sp * c.cout * Ntot;
@@ -698,15 +676,7 @@ int vy_net_bind_train(vy_net* net, void* dev_ws, size_t bytes, int32_t batch, in
   HIP_TRY(hipMemsetAsync(dev_ws, 0, need, s));
   static const int use_side = getenv("VY_TRAIN_SIDE_STREAM") ? atoi(getenv("VY_TRAIN_SIDE_STREAM")) : 1;
   if (use_side && !t->side) {
-    // VY_TRAIN_SIDE_PRIO: 0 default priority, 1 lowest (the weight gradients only fill what the
-    // BatchNorm / dgrad chain on the caller's stream leaves idle), -1 highest
-    static const int prio = getenv("VY_TRAIN_SIDE_PRIO") ? atoi(getenv("VY_TRAIN_SIDE_PRIO")) : 0;
-    int least = 0, greatest = 0;
-    HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
-    if (prio == 0)
-      HIP_TRY(hipStreamCreateWithFlags(&t->side, hipStreamNonBlocking));
-    else
-      HIP_TRY(hipStreamCreateWithPriority(&t->side, hipStreamNonBlocking, prio > 0 ? least : greatest));
+    HIP_TRY(hipStreamCreateWithFlags(&t->side, hipStreamNonBlocking));
     HIP_TRY(hipEventCreateWithFlags(&t->ev_main, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&t->ev_side, hipEventDisableTiming));
   }

@@ -29,8 +29,8 @@ __device__ __forceinline__ void lds_dma16(const float* gptr, unsigned lds_addr) 
 #endif
 }
 
-// KP = pixels per k-step (LDS stage): 32 -> 64 KiB double buffer (2 blocks / CU), 16 -> 32 KiB (4 blocks / CU,
-// which leaves room for the concurrently running dgrad blocks of the main stream)
+// KP = pixels per k-step (LDS stage): 32 -> 64 KiB double buffer, 2 blocks / CU.  (16 -> 32 KiB and 4 blocks / CU
+// was measured: faster alone, slower beside the dgrad chain it shares the chip with — 407 vs 414 frames/s.)
 template <int KP>
 __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a, const int tiles_n) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -173,13 +173,7 @@ hipError_t vy_launch_wgrad(const WgradArgs& a, hipStream_t s) {
     return hipErrorInvalidValue;
   const int Ntot = a.k * a.k * a.Cin;
   const int tiles_m = (a.Cout + 127) / 128, tiles_n = (Ntot + 127) / 128;
-  static const int kp = getenv("VY_WGRAD_KP") ? atoi(getenv("VY_WGRAD_KP")) : 32;
-  // experiment: unused dynamic LDS to cap the resident wgrad blocks per CU
-  static const int pad = getenv("VY_WGRAD_LDS_PAD") ? atoi(getenv("VY_WGRAD_LDS_PAD")) : 0;
-  if (kp == 16)
-    hipLaunchKernelGGL(wgrad_kernel<16>, dim3(tiles_m * tiles_n, a.splits), dim3(256), pad, s, a, tiles_n);
-  else
-    hipLaunchKernelGGL(wgrad_kernel<32>, dim3(tiles_m * tiles_n, a.splits), dim3(256), pad, s, a, tiles_n);
+  hipLaunchKernelGGL(wgrad_kernel<32>, dim3(tiles_m * tiles_n, a.splits), dim3(256), 0, s, a, tiles_n);
   return hipGetLastError();
 }
 
@@ -221,10 +215,7 @@ __global__ __launch_bounds__(32 * G) void slab_reduce_wide_kernel(const float* _
 }
 
 hipError_t vy_launch_slab_reduce(const float* slabs, int splits, long long n, float* dst, hipStream_t s) {
-  static const int wide = getenv("VY_SLAB_WIDE") ? atoi(getenv("VY_SLAB_WIDE")) : 1;
-  if (!wide)
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, slabs, splits, n, dst);
-  else if (splits >= 64)
+  if (splits >= 64)
     hipLaunchKernelGGL(slab_reduce_wide_kernel<32>, dim3((unsigned)((n + 31) / 32)), dim3(1024), 0, s, slabs, splits, n, dst);
   else if (splits >= 12)
     hipLaunchKernelGGL(slab_reduce_wide_kernel<8>, dim3((unsigned)((n + 31) / 32)), dim3(256), 0, s, slabs, splits, n, dst);
