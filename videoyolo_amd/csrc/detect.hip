@@ -11,8 +11,10 @@
 // and its sort key is (score, -r): box_nms orders by score descending and this implementation
 // breaks score ties by ascending r (a stable sort of the reference's tensor).
 //
-// Pipeline per batch (all images in parallel; every pass re-decodes from the 3 head planes,
-// 1.1-2.3 MB per image, instead of storing 5-16 MB of candidates per image):
+// Pipeline per batch (all images in parallel).  Pass 0 decodes every class score once from the 3 head
+// planes and keeps it ([B][C][anchors] fp32, 1.8 MB per image at 608/20 — a sixth of the reference's
+// candidate tensor, no boxes, no ids); the later passes and the collect read scores instead of paying
+// 1 + C sigmoids per anchor again:
 //   1. radix select of the k-th largest key, k = min(topk, #valid): pass 0 buckets the score
 //      linearly (1024 buckets, spreads LDS-atomic contention), passes 1-3 refine the score bits
 //      10 at a time inside the chosen bucket, passes 4-6 refine the inverted row index among
@@ -50,10 +52,11 @@ struct Entry {
 };
 
 struct Scratch {
-  // [B] SelState | [B][kBins] hist | [B][VY_NMS_MAX_TOPK] Entry
+  // [B] SelState | [B][kBins] hist | [B][VY_NMS_MAX_TOPK] Entry | [B][C][n_items] score
   SelState* st;
   uint32_t* hist;
   Entry* ent;
+  float* score;
 };
 
 __host__ __device__ inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -66,6 +69,8 @@ __host__ __device__ inline Scratch carve(void* base, int B) {
   s.hist = (uint32_t*)p;
   p += align256(sizeof(uint32_t) * (size_t)B * kBins);
   s.ent = (Entry*)p;
+  p += align256(sizeof(Entry) * (size_t)B * VY_NMS_MAX_TOPK);
+  s.score = (float*)p;
   return s;
 }
 
@@ -138,9 +143,16 @@ __global__ __launch_bounds__(kHistThreads) void hist_kernel(const DetArgs d, voi
     const int it = base + q * kHistThreads + threadIdx.x;
     Item im;
     if (it >= n_items || !locate(d, b, it, im)) continue;
-    const float conf = vy_sigmoidf(im.p[4]);
+    float* cache = sc.score + (size_t)b * d.C * n_items + it;  // [c][item]: coalesced across the block
+    const float conf = pass == 0 ? vy_sigmoidf(im.p[4]) : 0.0f;
     for (int c = 0; c < d.C; ++c) {
-      const float s = vy_sigmoidf(im.p[5 + c]) * conf;
+      float s;
+      if (pass == 0) {
+        s = vy_sigmoidf(im.p[5 + c]) * conf;
+        cache[(size_t)c * n_items] = s;
+      } else {
+        s = cache[(size_t)c * n_items];
+      }
       if (!(s > d.valid_thresh)) continue;
       const uint32_t sbits = vy_f32_to_bits(s);
       const uint32_t inv = ((1u << kIdxBits) - 1u) - (uint32_t)(im.cand0 + c * im.cstride);
@@ -239,11 +251,11 @@ __global__ __launch_bounds__(kHistThreads) void collect_kernel(const DetArgs d, 
     const int it = base + q * kHistThreads + threadIdx.x;
     Item im;
     if (it >= n_items || !locate(d, b, it, im)) continue;
-    const float conf = vy_sigmoidf(im.p[4]);
+    const float* cache = sc.score + (size_t)b * d.C * n_items + it;
     bool have_box = false;
     float x1 = 0, y1 = 0, x2 = 0, y2 = 0;
     for (int c = 0; c < d.C; ++c) {
-      const float s = vy_sigmoidf(im.p[5 + c]) * conf;
+      const float s = cache[(size_t)c * n_items];
       if (!(s > d.valid_thresh)) continue;
       const uint32_t sbits = vy_f32_to_bits(s);
       const uint32_t inv = ((1u << kIdxBits) - 1u) - (uint32_t)(im.cand0 + c * im.cstride);
@@ -386,9 +398,9 @@ __global__ __launch_bounds__(kNmsThreads) void sort_nms_kernel(const DetArgs d, 
 
 }  // namespace
 
-size_t vy_det_scratch_bytes(int B) {
+size_t vy_det_scratch_bytes(int B, int n_items, int C) {
   return align256(sizeof(SelState) * (size_t)B) + align256(sizeof(uint32_t) * (size_t)B * kBins) +
-         align256(sizeof(Entry) * (size_t)B * VY_NMS_MAX_TOPK);
+         align256(sizeof(Entry) * (size_t)B * VY_NMS_MAX_TOPK) + align256(sizeof(float) * (size_t)B * C * n_items);
 }
 
 hipError_t vy_launch_detect(const DetArgs& a, void* scratch, float* ids, float* scores, float* bboxes,

@@ -83,7 +83,7 @@ struct DetArgs {
   int topk, post_nms;
   int do_nms;           // 0: nms disabled (nms_thresh outside (0,1)): return first post_nms rows
 };
-size_t vy_det_scratch_bytes(int B);
+size_t vy_det_scratch_bytes(int B, int n_items, int C);  // n_items = anchors per image (N), C = classes
 // full tail: decode -> radix select of the top-k valid scores -> sort -> per-class NMS -> outputs
 hipError_t vy_launch_detect(const DetArgs& a, void* scratch, float* ids, float* scores, float* bboxes,
                             int32_t* keep_idx, hipStream_t s);

@@ -246,7 +246,9 @@ struct vy_net {
     const size_t fold_off = off;
     off += al(sizeof(FoldDesc) * folds.size());
     const size_t det_off = off;
-    off += al(vy_det_scratch_bytes(b));
+    int n_items = 0;
+    for (int i = 0; i < 3; ++i) n_items += 3 * (h / planes[head_plane[i]].div) * (w / planes[head_plane[i]].div);
+    off += al(vy_det_scratch_bytes(b, n_items, num_class));
     const size_t pl_off = off;
     size_t fl = 0;
     for (auto& p : planes) {
