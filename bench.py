@@ -252,7 +252,9 @@ def bench_train(args, vy, net, x, dev, dist, rank, world):
                    "classes": args.classes, "parallelism": "dp%d" % world,
                    "loss_rank0": float(sum(l.sum() for l in losses).item() / args.batch)},
     }
-    if rank == 0 and not args.no_roofline and fwd_gflop:
+    if not args.no_roofline and fwd_gflop:
+        # extra un-timed steps split into forward / backward / update by events; EVERY rank runs them (they
+        # contain the gradient and SyncBN collectives), rank 0 reports its own split
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
         fw, bw, up = [], [], []
         for _ in range(3):
