@@ -244,3 +244,40 @@ def test_two_stream_batch_split_is_identical(voc_classes, synth20):
     assert all(torch.equal(a, b) for a, b in zip(one, two))
     odd = net(x[:5])                      # odd batch: single-stream path
     assert odd[0].shape == (5, 40, 1)
+
+
+def test_api_surface_on_device(voc_classes, synth20, tmp_path):
+    """The object keeps working through the call patterns of the reference's scripts: changing batch and
+    image size between calls (replanning), hybridize() + set_nms() invalidation, deepcopy of a device net
+    (transforms.py:190), save -> load round trip, alternating training-mode and inference calls."""
+    import copy
+    import torch
+    from videoyolo_amd import autograd
+    net = _net(voc_classes, synth20)
+    xa, xb = frames(2, 96, seed=1), frames(3, 128, seed=2)
+    ra = [t.clone() for t in net(xa, return_index=True)]
+    rb = [t.clone() for t in net(xb, return_index=True)]
+    assert all(torch.equal(p, q) for p, q in zip(ra, net(xa, return_index=True)))      # back to the first plan
+    net.hybridize()
+    assert all(torch.equal(p, q) for p, q in zip(rb, net(xb, return_index=True)))
+    assert all(torch.equal(p, q) for p, q in zip(rb, net(xb, return_index=True)))      # graph replay
+    net.set_nms(0.45, 400, 50)                                                          # invalidates the graph
+    assert net(xb)[0].shape == (3, 50, 1)
+    net.set_nms(0.45, 400, 100)
+    assert all(torch.equal(p, q) for p, q in zip(ra, net(xa, return_index=True)))
+    net.hybridize(False)
+
+    twin = copy.deepcopy(net)                          # host-side copy with the same parameters
+    twin.collect_params().reset_ctx("cuda:0")
+    assert all(torch.equal(p, q) for p, q in zip(ra, twin(xa, return_index=True)))
+
+    path = str(tmp_path / "w.params")
+    net.save_parameters(path)
+    other = _net(voc_classes, {k: v * 0 + 0.5 for k, v in synth20.items()})
+    other.load_parameters(path)
+    assert all(torch.equal(p, q) for p, q in zip(ra, other(xa, return_index=True)))
+
+    with autograd.train_mode():                        # train-mode non-recording call (yolo3.py:1189-1192)
+        out = net(np.zeros((1, 3, 96, 96), np.float32))
+    assert len(out) == 8 and out[1][0].shape == (1, 1, 3, 2)
+    assert all(torch.equal(p, q) for p, q in zip(ra, net(xa, return_index=True)))      # inference unaffected
