@@ -146,3 +146,42 @@ def test_mxnet_params_container_roundtrip(voc_classes, tmp_path):
     from videoyolo_amd import mxparams
     d = mxparams.load(f)
     assert list(d)[0] == "stages.0.0.0.weight" and d["yolo_outputs.2.prediction.bias"].shape == (24,)
+
+
+def test_lr_schedule_of_the_training_script():
+    """The schedule train_yolov3.py:517-530 builds: linear warm-up from 0 to lr over warmup_epochs, then
+    'step' decay at the given epochs — values derived by hand (4 iterations per epoch, lr 0.1, 2 warm-up
+    epochs, 6 more epochs with x0.1 steps after 2 and 4 of them)."""
+    from videoyolo_amd import LRScheduler, LRSequential
+    n = 4
+    sched = LRSequential([
+        LRScheduler('linear', base_lr=0, target_lr=0.1, nepochs=2, iters_per_epoch=n),
+        LRScheduler('step', base_lr=0.1, nepochs=6, iters_per_epoch=n, step_epoch=[2, 4], step_factor=0.1, power=2)])
+    # warm-up: 8 updates, lr = 0.1 * t / 7
+    assert sched(0) == 0.0
+    assert abs(sched(7) - 0.1) < 1e-12 and abs(sched(3) - 0.1 * 3 / 7) < 1e-12
+    # step part starts at update 8 (its own T = num_update - 8): boundaries at T = 8 and 16
+    assert abs(sched(8) - 0.1) < 1e-12 and abs(sched(15) - 0.1) < 1e-12
+    assert abs(sched(16) - 0.01) < 1e-12 and abs(sched(23) - 0.01) < 1e-12
+    assert abs(sched(24) - 0.001) < 1e-12
+    assert abs(sched(10 ** 6) - 0.001) < 1e-12            # clamps at the end of the last scheduler
+    # the other modes at their end points and midpoint (niters = 11 -> N = 10)
+    for mode, mid in (('linear', 0.5), ('poly', 0.25), ('cosine', 0.5)):
+        s = LRScheduler(mode, base_lr=1.0, target_lr=0.0, niters=11, power=2)
+        assert abs(s(0) - 1.0) < 1e-12 and abs(s(10)) < 1e-12 and abs(s(5) - mid) < 1e-12
+    assert LRScheduler('constant', base_lr=0.3, niters=5)(3) == 0.3
+    import pytest as _pt
+    with _pt.raises(ValueError):
+        LRScheduler('step', base_lr=0.1, niters=10)
+    with _pt.raises(ValueError):
+        LRScheduler('exp')
+
+
+def test_trainer_uses_the_scheduler(voc_classes):
+    import videoyolo_amd as vy
+    net = _net(voc_classes[:2])
+    sched = vy.LRScheduler('linear', base_lr=1.0, target_lr=0.0, niters=11)
+    tr = vy.Trainer(net.collect_params(), 'sgd', {'wd': 5e-4, 'momentum': 0.9, 'lr_scheduler': sched})
+    assert tr.learning_rate == 1.0
+    with pytest.raises(UserWarning):
+        tr.set_learning_rate(0.5)
