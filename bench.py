@@ -194,6 +194,7 @@ def main():
     if rank == 0:
         print(json.dumps(result))
     if dist is not None:
+        dist.barrier()  # rank 0 may still be in its un-timed measurement passes: leave together
         dist.destroy_process_group()
 
 
@@ -279,6 +280,7 @@ def bench_train(args, vy, net, x, dev, dist, rank, world):
     if rank == 0:
         print(json.dumps(result))
     if dist is not None:
+        dist.barrier()  # rank 0 may still be in its un-timed measurement passes: leave together
         dist.destroy_process_group()
 
 
