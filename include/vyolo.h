@@ -109,6 +109,9 @@ int32_t vy_net_num_anchors(const vy_net* net);
  *   bboxes   device, (batch,post_nms,4)     corner format, input-pixel units, un-clipped
  *   keep_idx device, (batch,post_nms) int32, nullable: row index into the reference's
  *            pre-NMS (B, N*C, 6) detection tensor for every returned row (-1 for filler).
+ * With nms_thresh outside (0,1) the reference skips box_nms and the slice (yolo3.py:1197-1202): the
+ * outputs then have vy_net_num_anchors()*num_class rows — the (B, N*C, 6) detection tensor itself in its
+ * class-major row order — and keep_idx is the row number.
  * Asynchronous on `stream`. */
 int vy_net_forward_infer(vy_net* net, const float* x, float* ids, float* scores, float* bboxes,
                          int32_t* keep_idx, void* stream);

@@ -281,3 +281,19 @@ def test_api_surface_on_device(voc_classes, synth20, tmp_path):
         out = net(np.zeros((1, 3, 96, 96), np.float32))
     assert len(out) == 8 and out[1][0].shape == (1, 1, 3, 2)
     assert all(torch.equal(p, q) for p, q in zip(ra, net(xa, return_index=True)))      # inference unaffected
+
+
+def test_nms_disabled_returns_the_detection_tensor(voc_classes, synth20):
+    """set_nms(nms_thresh >= 1): the reference skips box_nms and the post_nms slice (yolo3.py:1197-1202) and
+    returns the (B, N*C, 6) detection tensor itself, class-major per scale."""
+    x = frames(2, 96, seed=9)
+    net = _net(voc_classes, synth20)
+    net.set_nms(1.0, 400, 100)
+    ids, scores, bboxes, keep = [t.cpu().numpy() for t in net(x, return_index=True)]
+    r_ids, r_scores, r_bboxes, _ = _oracle(synth20, nms_thresh=1.0)(x)
+    n = 3 * (3 * 3 + 6 * 6 + 12 * 12) * 20
+    assert ids.shape == (2, n, 1) and scores.shape == (2, n, 1) and bboxes.shape == (2, n, 4)
+    assert np.array_equal(ids, r_ids) and np.array_equal(scores, r_scores) and np.array_equal(bboxes, r_bboxes)
+    assert np.array_equal(keep, np.broadcast_to(np.arange(n, dtype=np.int32), (2, n)))
+    net.set_nms(0.45, 400, 100)                       # and back: the usual 100 rows
+    assert net(x)[0].shape == (2, 100, 1)

@@ -396,7 +396,41 @@ __global__ __launch_bounds__(kNmsThreads) void sort_nms_kernel(const DetArgs d, 
   }
 }
 
+// nms_thresh outside (0,1): the reference returns the un-suppressed detection tensor itself (yolo3.py:1195-1206
+// with the box_nms branch skipped): (B, N*C, 6) rows [id, score, x1, y1, x2, y2] in class-major order per scale.
+// One thread per anchor writes its C rows (its box once per class, like the reference's tile over classes).
+__global__ __launch_bounds__(kHistThreads) void raw_detections_kernel(const DetArgs d, int n_items, float* ids,
+                                                                      float* scores, float* bboxes,
+                                                                      int32_t* keep_idx) {
+  const int b = blockIdx.y;
+  const int it = blockIdx.x * kHistThreads + threadIdx.x;
+  Item im;
+  if (it >= n_items || !locate(d, b, it, im)) return;
+  const float conf = vy_sigmoidf(im.p[4]);
+  float x1, y1, x2, y2;
+  decode_box(d, im, x1, y1, x2, y2);
+  for (int c = 0; c < d.C; ++c) {
+    const size_t o = (size_t)b * d.n_cand + (size_t)(im.cand0 + c * im.cstride);
+    ids[o] = (float)c;
+    scores[o] = vy_sigmoidf(im.p[5 + c]) * conf;
+    bboxes[o * 4 + 0] = x1;
+    bboxes[o * 4 + 1] = y1;
+    bboxes[o * 4 + 2] = x2;
+    bboxes[o * 4 + 3] = y2;
+    if (keep_idx) keep_idx[o] = im.cand0 + c * im.cstride;
+  }
+}
+
 }  // namespace
+
+hipError_t vy_launch_raw_detections(const DetArgs& a, float* ids, float* scores, float* bboxes, int32_t* keep_idx,
+                                    hipStream_t s) {
+  int n_items = 0;
+  for (int i = 0; i < 3; ++i) n_items += a.head[i].H * a.head[i].W * 3;
+  dim3 grid((n_items + kHistThreads - 1) / kHistThreads, a.B);
+  hipLaunchKernelGGL(raw_detections_kernel, grid, dim3(kHistThreads), 0, s, a, n_items, ids, scores, bboxes, keep_idx);
+  return hipGetLastError();
+}
 
 size_t vy_det_scratch_bytes(int B, int n_items, int C) {
   return align256(sizeof(SelState) * (size_t)B) + align256(sizeof(uint32_t) * (size_t)B * kBins) +

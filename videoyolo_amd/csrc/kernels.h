@@ -85,6 +85,9 @@ struct DetArgs {
 };
 size_t vy_det_scratch_bytes(int B, int n_items, int C);  // n_items = anchors per image (N), C = classes
 // full tail: decode -> radix select of the top-k valid scores -> sort -> per-class NMS -> outputs
+// nms off: the full (B, N*C, .) detection tensor in the reference's row order
+hipError_t vy_launch_raw_detections(const DetArgs& a, float* ids, float* scores, float* bboxes, int32_t* keep_idx,
+                                    hipStream_t s);
 hipError_t vy_launch_detect(const DetArgs& a, void* scratch, float* ids, float* scores, float* bboxes,
                             int32_t* keep_idx, hipStream_t s);
 

@@ -373,11 +373,8 @@ struct vy_net {
   int forward(const float* x, float* ids, float* scores, float* bboxes, int32_t* keep_idx, hipStream_t s,
               Hook&& hook) {
     if (int rc = check_ready()) return rc;
-    if (!(nms_thresh > 0.f && nms_thresh < 1.f))
-      return fail(VY_ERR_UNSUPPORTED,
-                  "nms_thresh outside (0,1) returns the un-suppressed (B, N*C, 6) tensor in the reference "
-                  "(yolo3.py:1197); not provided by this path");
-    if (nms_topk <= 0 || nms_topk > VY_MAX_TOPK)
+    const bool nms_on = nms_thresh > 0.f && nms_thresh < 1.f;  // yolo3.py:1197
+    if (nms_on && (nms_topk <= 0 || nms_topk > VY_MAX_TOPK))
       return fail(VY_ERR_UNSUPPORTED, "nms_topk must be in [1, %d] (got %d)", VY_MAX_TOPK, nms_topk);
     FoldDesc* fd = reinterpret_cast<FoldDesc*>(dev_ws + fold_desc_off);
     if (!fold_uploaded) {
@@ -425,7 +422,10 @@ struct vy_net {
     double dby = 0;
     for (int i = 0; i < 3; ++i) dby += 4.0 * B * d.head[i].H * d.head[i].W * d.head[i].cs;
     hook("decode_nms", 0.0, dby, true);
-    HIP_TRY(vy_launch_detect(d, dev_ws + det_scratch_off, ids, scores, bboxes, keep_idx, s));
+    if (nms_on)
+      HIP_TRY(vy_launch_detect(d, dev_ws + det_scratch_off, ids, scores, bboxes, keep_idx, s));
+    else  // outputs are (B, N*C, .): the detection tensor itself
+      HIP_TRY(vy_launch_raw_detections(d, ids, scores, bboxes, keep_idx, s));
     hook("decode_nms", 0.0, dby, false);
     return 0;
   }

@@ -444,6 +444,13 @@ class YOLOV3(object):
         self._plan = (b, h, w, bool(train))
         self._graphs = {}
 
+    def _out_rows(self):
+        """Rows of the inference outputs: post_nms (or nms_topk) after box_nms; with nms_thresh outside (0,1)
+        the reference returns the whole (B, N*C, 6) detection tensor (yolo3.py:1197-1202)."""
+        if 0 < self.nms_thresh < 1:
+            return self.post_nms if self.post_nms > 0 else self.nms_topk
+        return int(self._lib.vy_net_num_anchors(self._h)) * len(self._classes)
+
     def _as_input(self, x):
         torch = _torch()
         if not isinstance(x, torch.Tensor):
@@ -569,7 +576,7 @@ class YOLOV3(object):
         with torch.cuda.device(self._device):
             replanned = self._plan is None or self._plan[:3] != (b, h, w)
             self._ensure_plan(b, h, w)
-            rows = self.post_nms if self.post_nms > 0 else self.nms_topk
+            rows = self._out_rows()
             if getattr(self, "_hybrid", False) and self._use_graphs:
                 if replanned:
                     self._graphs = {}
@@ -621,7 +628,7 @@ class YOLOV3(object):
                 _lib.check(self._lib.vy_net_bind_workspace(tw["h"], ctypes.c_void_p(tw["ws"].data_ptr()),
                                                            tw["ws"].numel(), hb, h, w, ctypes.c_void_p(cur.cuda_stream)))
                 tw["plan"] = (hb, h, w)
-            rows = self.post_nms if self.post_nms > 0 else self.nms_topk
+            rows = self._out_rows()
             ids = torch.empty((b, rows, 1), dtype=torch.float32, device=self._device)
             scores = torch.empty((b, rows, 1), dtype=torch.float32, device=self._device)
             bboxes = torch.empty((b, rows, 4), dtype=torch.float32, device=self._device)
@@ -673,7 +680,7 @@ class YOLOV3(object):
         b, _, h, w = x.shape
         with torch.cuda.device(self._device):
             self._ensure_plan(b, h, w)
-            rows = self.post_nms if self.post_nms > 0 else self.nms_topk
+            rows = self._out_rows()
             ids = torch.empty((b, rows, 1), dtype=torch.float32, device=self._device)
             scores = torch.empty_like(ids)
             bboxes = torch.empty((b, rows, 4), dtype=torch.float32, device=self._device)
