@@ -297,3 +297,35 @@ def test_nms_disabled_returns_the_detection_tensor(voc_classes, synth20):
     assert np.array_equal(keep, np.broadcast_to(np.arange(n, dtype=np.int32), (2, n)))
     net.set_nms(0.45, 400, 100)                       # and back: the usual 100 rows
     assert net(x)[0].shape == (2, 100, 1)
+
+
+def test_denormal_range_is_kept():
+    """Products and sums in the fp32 subnormal range (weights 1e-30, inputs 1e-9): the matrix-core fma chain
+    keeps them exactly like the CPU checker's fmaf chain — no flush to zero."""
+    from videoyolo_amd import init
+    from oracle import yolo3_oracle as O
+    classes = ["a", "b", "c"]
+    params = init.synthetic_params(O.param_shapes(3), seed=1)
+    params["stages.0.0.0.weight"] = (params["stages.0.0.0.weight"] * 1e-30).astype(np.float32)
+    params["stages.0.0.1.gamma"][:] = 1
+    params["stages.0.0.1.beta"][:] = 0
+    params["stages.0.0.1.running_mean"][:] = 0
+    params["stages.0.0.1.running_var"][:] = 1
+    x = (np.random.default_rng(0).standard_normal((1, 3, 64, 64)) * 1e-9).astype(np.float32)
+    net = _net(classes, params)
+    net(x)
+    orc = _oracle(params, 3)
+    taps = {}
+    cell0 = orc.cell
+
+    def cell(xx, pre, *a, **k):
+        y = cell0(xx, pre, *a, **k)
+        taps[pre] = y
+        return y
+    orc.cell = cell
+    orc.raw_heads(x)
+    want = taps["stages.0.0"]
+    got = net.read_activation("stages.0.0").cpu().numpy()
+    sub = (np.abs(want) < np.finfo(np.float32).tiny) & (want != 0)
+    assert sub.sum() > 1000, "the case must actually exercise subnormals"
+    assert np.array_equal(got, want)
