@@ -3,7 +3,18 @@
 (SURVEY.md §8f row 1).  TEST INFRASTRUCTURE ONLY.  Follows the reference loop literally, including
 int() truncation (:115-116), max(gtw, 1) (:121), the weight 2 - w*h/(W*H) (:123) and the break at
 the first invalid gt row (:107-108).  nd.contrib.box_iou is restated as corner IoU without +1
-[UPSTREAM-RECALLED]."""
+[UPSTREAM-RECALLED]; BBoxCornerToCenter (gluoncv.nn.bbox) as fp32 `xmin + width / 2` [UPSTREAM-RECALLED].
+
+Scalar types.  The reference pins Python 3.6.3 (environment.yml:6), i.e. NumPy 1.x, where an
+np.float32 SCALAR combined with a Python int is promoted to float64 (both operands are scalars, so
+value-based casting does not apply).  Hence in the loop (:115-123)
+  gtx / orig_width * width                  float64   -> int() truncates the float64 value
+  gtx / orig_width * width - loc_x          float64   -> rounded to fp32 by the NDArray store
+  max(gtw, 1) / np_anchors[match, 0]        float32 / float32 when gtw >= 1 (max returns gtw);
+                                            int / float32 = float64 when 1 > gtw
+  2.0 - gtw * gth / orig_width / orig_height   fp32 product, then float64
+This container has NumPy 2.x (NEP 50: Python ints are weak, everything would stay fp32), so the
+float64 steps are written out explicitly below."""
 import numpy as np
 
 from . import yolo3_oracle as O
@@ -50,10 +61,11 @@ def prefetch_targets(num_class, height, width, gt_boxes, gt_ids, gt_mixratio=Non
     weights = np.zeros_like(center_targets)
     objectness = np.zeros((B, ncell, 9, 1), np.float32)
     class_targets = np.full((B, ncell, 9, num_class), -1, np.float32)
-    gtx = (gt_boxes[..., 0] + gt_boxes[..., 2]) / 2  # BBoxCornerToCenter
-    gty = (gt_boxes[..., 1] + gt_boxes[..., 3]) / 2
-    gtw = gt_boxes[..., 2] - gt_boxes[..., 0]
+    gt_boxes = np.asarray(gt_boxes, np.float32)
+    gtw = gt_boxes[..., 2] - gt_boxes[..., 0]        # BBoxCornerToCenter, fp32 NDArray arithmetic
     gth = gt_boxes[..., 3] - gt_boxes[..., 1]
+    gtx = gt_boxes[..., 0] + gtw / np.float32(2)
+    gty = gt_boxes[..., 1] + gth / np.float32(2)
     valid = (gt_boxes >= 0).prod(axis=-1)
     for b in range(B):
         ious = _iou_centered(all_anchors, np.stack([gtw[b], gth[b]], -1))  # (9,M)
@@ -65,14 +77,17 @@ def prefetch_targets(num_class, height, width, gt_boxes, gt_ids, gt_mixratio=Non
             nlayer = int(np.nonzero(num_anchors > match)[0][0])
             h, w = fms[nlayer]
             x, y, bw, bh = gtx[b, m], gty[b, m], gtw[b, m], gth[b, m]
-            loc_x = int(x / width * w)
-            loc_y = int(y / height * h)
+            fx = float(x) / width * w      # float64 (see the module docstring)
+            fy = float(y) / height * h
+            loc_x = int(fx)
+            loc_y = int(fy)
             index = _offsets[nlayer] + loc_y * w + loc_x
-            center_targets[b, index, match, 0] = x / width * w - loc_x
-            center_targets[b, index, match, 1] = y / height * h - loc_y
-            scale_targets[b, index, match, 0] = np.log(max(bw, 1) / all_anchors[match, 0])
-            scale_targets[b, index, match, 1] = np.log(max(bh, 1) / all_anchors[match, 1])
-            weights[b, index, match, :] = 2.0 - bw * bh / width / height
+            center_targets[b, index, match, 0] = fx - loc_x
+            center_targets[b, index, match, 1] = fy - loc_y
+            aw, ah = all_anchors[match, 0], all_anchors[match, 1]
+            scale_targets[b, index, match, 0] = np.log(bw / aw) if not 1 > bw else np.log(1 / float(aw))
+            scale_targets[b, index, match, 1] = np.log(bh / ah) if not 1 > bh else np.log(1 / float(ah))
+            weights[b, index, match, :] = 2.0 - float(bw * bh) / width / height
             objectness[b, index, match, 0] = gt_mixratio[b, m, 0] if gt_mixratio is not None else 1
             class_targets[b, index, match, :] = 0
             class_targets[b, index, match, int(gt_ids[b, m, 0])] = 1

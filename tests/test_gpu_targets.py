@@ -58,6 +58,17 @@ def test_device_targets_edge_cases():
     assert got[0][0].sum() == 1 and got[0][1].sum() == 2
 
 
+def test_device_cell_index_follows_float64_promotion():
+    """Centres where int(fp32 quotient) != int(float64 quotient): the kernel must pick the float64 cell
+    (yolo_target.py:115-119 under the reference's NumPy 1.x scalar promotion) — an index, so exact."""
+    from conftest import check_float64_cell_case, float64_cell_case
+    from oracle import targets_oracle as T
+    size, gt, ids, expected = float64_cell_case()
+    got = _device(4, size, gt, ids)
+    check_float64_cell_case(got, expected)
+    _check(got, T.prefetch_targets(4, size, size, gt, ids))
+
+
 def test_device_targets_by_hand():
     """One gt box (8,8)-(40,24), class 1, in a 64x64 image: w=32, h=16 -> best zero-centred IoU among
     the nine anchors is (33,23), the last one -> stride-8 scale (8x8 cells), anchor slot 2; centre

@@ -29,6 +29,19 @@ def test_prefetch_targets_match_the_reference_loop():
     assert targets.num_anchors(416, 416) == 10647 and targets.num_anchors(608, 608) == 22743
 
 
+def test_cell_index_follows_float64_promotion():
+    """yolo_target.py:115-119 under NumPy 1.x: the cell is int() of a FLOAT64 quotient.  Centres on
+    stride multiples where fp32 and float64 truncate differently must land in the float64 cell, in the
+    oracle and in the host generator alike (the device kernel: tests/test_gpu_targets.py)."""
+    from conftest import check_float64_cell_case, float64_cell_case
+    size, gt, ids, expected = float64_cell_case()
+    # the case is only a test if fp32 arithmetic really disagrees on some cell
+    f32 = [int(np.float32(240.0) / np.float32(416) * np.float32(26)), int(np.float32(120.0) / np.float32(416) * np.float32(52))]
+    assert f32 == [15, 15] and [expected[0][2], expected[1][3]] == [14, 14]
+    check_float64_cell_case(TOr.prefetch_targets(4, size, size, gt, ids), expected)
+    check_float64_cell_case(targets.YOLOV3PrefetchTargetGenerator(4)(size, size, gt, ids), expected)
+
+
 def test_split_sizes_even_split_false():
     assert parallel.split_sizes(64, 8) == [8] * 8
     assert parallel.split_sizes(10, 4) == [3, 3, 2, 2]         # gluon split_data(even_split=False)

@@ -12,7 +12,13 @@
 // image.  The reference loop is sequential — a later gt box landing in the same (cell, anchor) slot
 // overwrites the earlier one completely, and the loop stops at the first padded row (:107-108); here
 // every box computes its slot in parallel and only the LAST valid box of each slot writes.
-// fp32 arithmetic in the reference's operation order (no contraction), log via include/vy_math.h.
+// Arithmetic types follow the reference under its pinned interpreter (Python 3.6.3, environment.yml:6 =>
+// NumPy 1.x scalar promotion): gtx/gty/gtw/gth are np.float32 scalars (fp32 BBoxCornerToCenter), but
+// `gtx / orig_width * width` mixes them with Python ints and is evaluated in float64 (:115-119), as is
+// `2.0 - gtw * gth / orig_width / orig_height` after the fp32 product (:123) and `1 / anchor` when
+// max(gtw, 1) returns the Python int (:121-122).  The cell index is int() of the float64 value and the
+// centre target is the float64 remainder rounded to fp32 on the store.  No contraction; fp32 log via
+// include/vy_math.h.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -71,7 +77,7 @@ __global__ __launch_bounds__(64) void targets_scatter_kernel(const TargetArgs a)
   for (int m = t; m < nvalid; m += 64) {
     const float x1 = gb[m * 4 + 0], y1 = gb[m * 4 + 1], x2 = gb[m * 4 + 2], y2 = gb[m * 4 + 3];
     const float gw = x2 - x1, gh = y2 - y1;
-    const float gx = (x1 + x2) / 2.0f, gy = (y1 + y2) / 2.0f;
+    const float gx = x1 + gw / 2.0f, gy = y1 + gh / 2.0f;  // gluoncv BBoxCornerToCenter: xmin + width / 2
     // best anchor: first maximum of IoU(zero-centred anchor, zero-centred gt) = argmax (:92-94)
     int match = 0;
     float best = -1.0f;
@@ -86,8 +92,8 @@ __global__ __launch_bounds__(64) void targets_scatter_kernel(const TargetArgs a)
       }
     }
     const int l = match / 3;
-    const float fx = gx / (float)a.W * (float)a.fw[l];
-    const float fy = gy / (float)a.H * (float)a.fh[l];
+    const double fx = (double)gx / (double)a.W * (double)a.fw[l];  // float64: np.float32 scalar / Python int
+    const double fy = (double)gy / (double)a.H * (double)a.fh[l];
     const int lx = (int)fx, ly = (int)fy;
     const long long cell = (long long)ly * a.fw[l] + lx;
     // a centre on the right / bottom edge indexes past its row: the reference then writes a (cell,
@@ -107,18 +113,19 @@ __global__ __launch_bounds__(64) void targets_scatter_kernel(const TargetArgs a)
     if (!last) continue;
     const float x1 = gb[m * 4 + 0], y1 = gb[m * 4 + 1], x2 = gb[m * 4 + 2], y2 = gb[m * 4 + 3];
     const float gw = x2 - x1, gh = y2 - y1;
-    const float gx = (x1 + x2) / 2.0f, gy = (y1 + y2) / 2.0f;
+    const float gx = x1 + gw / 2.0f, gy = y1 + gh / 2.0f;
     int l = 0;
     while (l < 2 && n >= a.base[l + 1]) ++l;
     const int match = 3 * l + (n - a.base[l]) % 3;
-    const float fx = gx / (float)a.W * (float)a.fw[l];
-    const float fy = gy / (float)a.H * (float)a.fh[l];
+    const double fx = (double)gx / (double)a.W * (double)a.fw[l];
+    const double fy = (double)gy / (double)a.H * (double)a.fh[l];
     const long long row = (long long)b * a.N + n;
-    a.ctr[row * 2 + 0] = fx - (float)(int)fx;
-    a.ctr[row * 2 + 1] = fy - (float)(int)fy;
-    a.scl[row * 2 + 0] = vy_logf(fmaxf(gw, 1.0f) / kAnchorW[match]);
-    a.scl[row * 2 + 1] = vy_logf(fmaxf(gh, 1.0f) / kAnchorH[match]);
-    const float wt = 2.0f - gw * gh / (float)a.W / (float)a.H;
+    a.ctr[row * 2 + 0] = (float)(fx - (double)(int)fx);
+    a.ctr[row * 2 + 1] = (float)(fy - (double)(int)fy);
+    // max(gtw, 1) is the np.float32 gtw unless 1 > gtw; then it is the Python int and 1 / anchor is float64
+    a.scl[row * 2 + 0] = gw >= 1.0f ? vy_logf(gw / kAnchorW[match]) : (float)log(1.0 / (double)kAnchorW[match]);
+    a.scl[row * 2 + 1] = gh >= 1.0f ? vy_logf(gh / kAnchorH[match]) : (float)log(1.0 / (double)kAnchorH[match]);
+    const float wt = (float)(2.0 - (double)(gw * gh) / (double)a.W / (double)a.H);
     a.wts[row * 2 + 0] = wt;
     a.wts[row * 2 + 1] = wt;
     a.obj[row] = a.gt_mix ? a.gt_mix[(long long)b * a.M + m] : 1.0f;

@@ -5,9 +5,11 @@ Host-side mirror of ``YOLOV3PrefetchTargetGenerator`` (models/definitions/yolo/y
 which the reference runs in DataLoader worker processes (train_yolov3.py:260-271,
 models/definitions/yolo/transforms.py:185-197,259-277).  Same host language (Python/numpy), but
 vectorised over the batch and the gt boxes instead of the reference's Python double loop; the
-quirks that decide the numbers are kept: centre -> cell by int() truncation (:115-116),
-log(max(w,1)/anchor) (:121-122), weight 2 - w*h/(W*H) (:123), later gt boxes overwrite earlier ones
-in the same (cell, anchor) slot, and rows after the first invalid (-1) gt box are ignored (:107-108).
+quirks that decide the numbers are kept: centre -> cell by int() truncation of the FLOAT64 value
+`gtx / orig_width * width` (:115-116; an np.float32 scalar with Python ints is float64 under the
+reference's pinned NumPy 1.x), log(max(w,1)/anchor) (:121-122), weight 2 - w*h/(W*H) (:123, fp32
+product then float64), later gt boxes overwrite earlier ones in the same (cell, anchor) slot, and rows
+after the first invalid (-1) gt box are ignored (:107-108).
 """
 import numpy as np
 
@@ -46,8 +48,8 @@ class YOLOV3PrefetchTargetGenerator(object):
             return obj, ctr, scl, wts, cls
         gtw = gt_boxes[..., 2] - gt_boxes[..., 0]
         gth = gt_boxes[..., 3] - gt_boxes[..., 1]
-        gtx = (gt_boxes[..., 0] + gt_boxes[..., 2]) / 2
-        gty = (gt_boxes[..., 1] + gt_boxes[..., 3]) / 2
+        gtx = gt_boxes[..., 0] + gtw / np.float32(2)  # gluoncv BBoxCornerToCenter, fp32
+        gty = gt_boxes[..., 1] + gth / np.float32(2)
         # best anchor by IoU of zero-centred boxes: inter = min(w)*min(h) (both centred at 0)
         iw = np.minimum(gtw[..., None], ANCHORS[:, 0])
         ih = np.minimum(gth[..., None], ANCHORS[:, 1])
@@ -60,13 +62,16 @@ class YOLOV3PrefetchTargetGenerator(object):
         layer = match // 3
         stride = np.array(STRIDES)[layer]
         fw, fh = width // stride, height // stride
-        # float64 division then truncation, as Python's int(gtx / orig_width * width) does
-        fx = gtx.astype(np.float32) / np.float32(width) * fw.astype(np.float32)
-        fy = gty.astype(np.float32) / np.float32(height) * fh.astype(np.float32)
+        # float64 division then truncation, as int(gtx / orig_width * width) does under NumPy 1.x
+        fx = gtx.astype(np.float64) / float(width) * fw.astype(np.float64)
+        fy = gty.astype(np.float64) / float(height) * fh.astype(np.float64)
         loc_x, loc_y = fx.astype(np.int64), fy.astype(np.int64)
         cells = np.array([0] + list(np.cumsum([(height // s) * (width // s) for s in STRIDES])))[:-1]
         base = np.array([0] + list(np.cumsum([3 * (height // s) * (width // s) for s in STRIDES])))[:-1]
         n_idx = base[layer] + (loc_y * fw + loc_x) * 3 + (match % 3)
+        # a centre on the right / bottom image edge indexes past its scale's cells: the reference writes a
+        # (cell, anchor) pair there that `_slice` (:139-148) discards
+        valid &= (loc_y * fw + loc_x) < fw * fh
         del cells
         anc = ANCHORS[match]
         for b in range(B):  # in-order assignment so later boxes overwrite earlier ones
@@ -74,9 +79,9 @@ class YOLOV3PrefetchTargetGenerator(object):
                 n = n_idx[b, m]
                 ctr[b, n, 0] = fx[b, m] - loc_x[b, m]
                 ctr[b, n, 1] = fy[b, m] - loc_y[b, m]
-                scl[b, n, 0] = np.log(max(gtw[b, m], 1) / anc[b, m, 0])
-                scl[b, n, 1] = np.log(max(gth[b, m], 1) / anc[b, m, 1])
-                wts[b, n, :] = 2.0 - gtw[b, m] * gth[b, m] / width / height
+                for j, g in enumerate((gtw[b, m], gth[b, m])):
+                    scl[b, n, j] = np.log(g / anc[b, m, j]) if g >= 1 else np.log(1.0 / float(anc[b, m, j]))
+                wts[b, n, :] = 2.0 - float(gtw[b, m] * gth[b, m]) / width / height
                 obj[b, n, 0] = gt_mixratio[b, m, 0] if gt_mixratio is not None else 1
                 cls[b, n, :] = 0
                 cls[b, n, int(gt_ids[b, m, 0])] = 1
