@@ -6,8 +6,9 @@
 One "step" = one inference pass of the whole path (stem + 74 fused conv launches + decode + NMS)
 over one batch of synthetic frames that is already resident in HBM.  Default workload is
 BASELINE.json configs[1]: 608x608, batch 64 per GPU, 20 classes, fp32, random-init weights
-(videoyolo_amd.init 'synthetic', seed 233), N(0,1) frames.  With --gpus N the driver starts one
-process per GPU (torch.distributed.run); frames are scattered, every rank runs its own batch
+(videoyolo_amd.init 'synthetic', seed 233), N(0,1) frames.  With --gpus N there is one
+process per GPU: either the driver starts them (torch.distributed.run) or, run plainly as
+`python bench.py --gpus N`, this script starts its own N rank processes; frames are scattered, every rank runs its own batch
 (weak scaling, no data-path collective — SURVEY §8e "Inference"), the timed region is bracketed
 by barrier + synchronize and the max over ranks is reported.
 
@@ -50,6 +51,12 @@ def main():
     ap.add_argument("--share-gpu", action="store_true",
                     help="testing only: all ranks use cuda:0 (with --backend gloo) to exercise the N>1 code path on one GPU")
     args = ap.parse_args()
+    # `python bench.py --gpus N` (no rank environment): this process only starts the N ranks and waits —
+    # it never touches a GPU and never execs (videoyolo_amd/launch.py).  Under torch.distributed.run the
+    # rank environment is already there and this is skipped.
+    from videoyolo_amd import launch
+    if launch.needs_spawn(args.gpus):
+        sys.exit(launch.spawn_ranks(args.gpus, [os.path.abspath(__file__)] + sys.argv[1:]))
     if args.mode == "train":
         if "--size" not in " ".join(sys.argv):
             args.size = 416
@@ -64,9 +71,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be started by torch.distributed.run with %d ranks" %
-                     (args.gpus, args.gpus))
+        sys.exit("bench.py --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -263,7 +268,7 @@ def bench_train(args, vy, net, x, dev, dist, rank, world):
             with autograd.record():
                 losses = net(x, *dv)
                 ev[1].record()
-                autograd.backward([losses[0]])
+                autograd.backward([losses[0] + losses[1] + losses[2] + losses[3]])
             ev[2].record()
             trainer.step(global_batch)
             ev[3].record()

@@ -69,8 +69,14 @@ const char* vy_version(void);
 int vy_net_create(int32_t num_class, vy_net** out);
 void vy_net_destroy(vy_net* net);
 
-/* net.set_nms(nms_thresh, nms_topk, post_nms) — yolo3.py:1208-1228.  nms_topk <= 0 selects
- * every valid candidate (capped at VY_MAX_TOPK); post_nms <= 0 returns nms_topk rows. */
+/* net.set_nms(nms_thresh, nms_topk, post_nms) — yolo3.py:1208-1228.
+ *   nms_topk in [1, VY_MAX_TOPK]   the nms_topk best valid candidates go through NMS (the scripts use 400)
+ *   nms_topk <= 0                  "-1 to disable": EVERY valid candidate goes through NMS (consumed in
+ *                                  score order in chunks of VY_MAX_TOPK until post_nms rows are kept); needs
+ *                                  post_nms in [1, VY_MAX_TOPK] — the un-sliced result would have N*C rows
+ *   nms_topk > VY_MAX_TOPK         rejected by the forward (VY_ERR_UNSUPPORTED)
+ *   post_nms <= 0                  the outputs have nms_topk rows (no slice, yolo3.py:1201-1202)
+ *   nms_thresh outside (0, 1)      no NMS at all: see vy_net_forward_infer */
 #define VY_MAX_TOPK 1024
 int vy_net_set_nms(vy_net* net, float nms_thresh, int32_t nms_topk, int32_t post_nms);
 
@@ -195,6 +201,17 @@ int vy_net_set_train_options(vy_net* net, float ignore_iou_thresh, int32_t label
 int vy_net_train_forward(vy_net* net, const float* x, const float* gt_boxes, int32_t M,
                          const float* obj_t, const float* centers_t, const float* scales_t,
                          const float* weights_t, const float* clas_t, float* losses, void* stream);
+
+/* net(x) under autograd.train_mode() without recording — yolo3.py:1189-1192, the branch the DataLoader
+ * transform drives (transforms.py:190-193): the network runs with BatchNorm on batch statistics (running
+ * stats updated, as mxnet's BatchNorm does whenever is_training), and the per-anchor tensors of
+ * YOLOOutputV3's training return (yolo3.py:179-182) come back concatenated over the scales (stride 32, 16,
+ * 8 -> cell -> anchor):  box_preds (B,N,4) decoded corner boxes, centers (B,N,2) / scales (B,N,2) /
+ * objness (B,N,1) / class_pred (B,N,C) RAW predictions.  Items 1-3 of the reference's 8-tuple (anchors,
+ * offsets, fake feature maps) are constants of the input shape and are built by the host mirror.
+ * Needs the training workspace (vy_net_bind_train).  All outputs are device buffers. */
+int vy_net_train_mode_forward(vy_net* net, const float* x, float* box_preds, float* centers, float* scales,
+                              float* objness, float* class_pred, void* stream);
 
 /* autograd.backward(sum_losses) (train_yolov3.py:631): fills the gradient buffer (every trainable
  * tensor, device layout) from the state left by the last vy_net_train_forward.  `x` is the same

@@ -59,12 +59,31 @@ class OracleYolo3Train(O.OracleYolo3):
     BN_EPS = 1e-5
     RUNNING_VAR_UNBIASED = False  # [UPSTREAM-RECALLED] mxnet CPU BatchNorm keeps the biased variance
 
-    def __init__(self, num_class, params, ignore_iou_thresh=0.7, label_smooth=False):
+    def __init__(self, num_class, params, ignore_iou_thresh=0.7, label_smooth=False, device_slices=None,
+                 sync_bn=False):
+        """device_slices: data parallelism as the reference runs it (split_and_load, train_yolov3.py:603-606) —
+        a list of batch-axis slices, one per device.  Every BatchNorm then normalises with the statistics of
+        ITS device's slice, except — with sync_bn (SyncBatchNorm(num_devices), train_yolov3.py:352-354) — the
+        layers that are actually built from the passed norm_layer: the stem and the five stride-2 convs of
+        Darknet-53 (three_darknet.py:163-181; the residual blocks hard-code BatchNorm :193-194 and
+        wrappers.py:101-103 does not forward norm_layer to the heads), which use the whole batch.  Gradients
+        are the sums over all devices (Trainer kvstore reduce)."""
         super().__init__(num_class, params)
         self.ignore_iou_thresh = ignore_iou_thresh
         self.label_smooth = label_smooth
+        self.device_slices = device_slices
+        self.sync_bn = sync_bn
         self.tape = []
         self.new_running = {}
+        self.new_running_dev = []
+
+    def _stat_groups(self, pre, batch):
+        """batch-axis slices over which the BatchNorm of cell `pre` takes its statistics"""
+        whole = [slice(0, batch)]
+        if not self.device_slices:
+            return whole
+        synced = self.sync_bn and pre.startswith("stages.") and ".body." not in pre
+        return whole if synced else list(self.device_slices)
 
     # ---------------------------------------------------------------- forward (recording)
     def cell(self, x, pre, k, stride):
@@ -72,19 +91,34 @@ class OracleYolo3Train(O.OracleYolo3):
         w = self.p[pre + ".0.weight"]
         z = O.conv2d(x, w, stride, k // 2)
         g, b = self.p[pre + ".1.gamma"], self.p[pre + ".1.beta"]
-        y, mean, var = O.bn_train(z, g, b, self.BN_EPS, leaky=True)
-        n = z.shape[0] * z.shape[2] * z.shape[3]
-        rv = var * (n / max(n - 1, 1)) if self.RUNNING_VAR_UNBIASED else var
+        groups = self._stat_groups(pre, z.shape[0])
+        y = np.empty_like(z)
+        means, vars_ = [], []
         m = np.float32(self.BN_MOMENTUM)
-        self.new_running[pre + ".1.running_mean"] = self.p[pre + ".1.running_mean"] * m + mean * (1 - m)
-        self.new_running[pre + ".1.running_var"] = self.p[pre + ".1.running_var"] * m + rv * (1 - m)
-        self.tape.append(dict(kind="cell", pre=pre, k=k, s=stride, x=x, z=z, mean=mean, var=var, out=y))
+        ndev = len(self.device_slices) if self.device_slices else 1
+        while len(self.new_running_dev) < ndev:
+            self.new_running_dev.append({})
+        for gi, sl in enumerate(groups):
+            y[sl], mean, var = O.bn_train(z[sl], g, b, self.BN_EPS, leaky=True)
+            n = z[sl].shape[0] * z.shape[2] * z.shape[3]
+            rv = var * (n / max(n - 1, 1)) if self.RUNNING_VAR_UNBIASED else var
+            new = {pre + ".1.running_mean": self.p[pre + ".1.running_mean"] * m + mean * (1 - m),
+                   pre + ".1.running_var": self.p[pre + ".1.running_var"] * m + rv * (1 - m)}
+            # every device keeps its own running statistics; a layer normalised over the whole batch
+            # gives all devices the same ones
+            for d in (range(ndev) if len(groups) == 1 else [gi]):
+                self.new_running_dev[d].update(new)
+            means.append(mean)
+            vars_.append(var)
+        self.new_running.update({k: v for k, v in self.new_running_dev[0].items() if k.startswith(pre + ".1.")})
+        self.tape.append(dict(kind="cell", pre=pre, k=k, s=stride, x=x, z=z, mean=means, var=vars_, groups=groups,
+                              out=y))
         return y
 
     def forward_raw(self, x):
         """Runs stages + heads in train mode.  Returns per-scale prediction conv outputs and keeps
         the graph on self.tape (a DAG walked in reverse by backward())."""
-        self.tape, self.new_running = [], {}
+        self.tape, self.new_running, self.new_running_dev = [], {}, []
         x = O._c(x)
         feats = O.darknet_feature_cells()
         routes = []
@@ -208,21 +242,26 @@ class OracleYolo3Train(O.OracleYolo3):
 
     # ---------------------------------------------------------------- backward
     def _cell_bwd(self, t, da, grads):
-        pre, z = t["pre"], t["z"].astype(np.float64)
+        pre = t["pre"]
         g = self.p[pre + ".1.gamma"].astype(np.float64).reshape(1, -1, 1, 1)
         b = self.p[pre + ".1.beta"].astype(np.float64).reshape(1, -1, 1, 1)
-        mean = t["mean"].astype(np.float64).reshape(1, -1, 1, 1)
-        inv = 1.0 / np.sqrt(t["var"].astype(np.float64).reshape(1, -1, 1, 1) + self.BN_EPS)
-        xhat = (z - mean) * inv
-        y = xhat * g + b
-        dy = da.astype(np.float64) * np.where(y > 0, 1.0, 0.1)
-        n = z.shape[0] * z.shape[2] * z.shape[3]
-        dbeta = dy.sum(axis=(0, 2, 3))
-        dgamma = (dy * xhat).sum(axis=(0, 2, 3))
-        dz = g * inv * (dy - dbeta.reshape(1, -1, 1, 1) / n - xhat * dgamma.reshape(1, -1, 1, 1) / n)
-        dz = dz.astype(np.float32)
-        grads[pre + ".1.gamma"] = dgamma.astype(np.float32)
-        grads[pre + ".1.beta"] = dbeta.astype(np.float32)
+        dz = np.empty(t["z"].shape, np.float32)
+        dbeta_tot, dgamma_tot = 0.0, 0.0
+        for sl, mean, var in zip(t["groups"], t["mean"], t["var"]):  # one statistics group per device (or one)
+            z = t["z"][sl].astype(np.float64)
+            mean = mean.astype(np.float64).reshape(1, -1, 1, 1)
+            inv = 1.0 / np.sqrt(var.astype(np.float64).reshape(1, -1, 1, 1) + self.BN_EPS)
+            xhat = (z - mean) * inv
+            y = xhat * g + b
+            dy = da[sl].astype(np.float64) * np.where(y > 0, 1.0, 0.1)
+            n = z.shape[0] * z.shape[2] * z.shape[3]
+            dbeta = dy.sum(axis=(0, 2, 3))
+            dgamma = (dy * xhat).sum(axis=(0, 2, 3))
+            dz[sl] = (g * inv * (dy - dbeta.reshape(1, -1, 1, 1) / n - xhat * dgamma.reshape(1, -1, 1, 1) / n)
+                      ).astype(np.float32)
+            dbeta_tot, dgamma_tot = dbeta_tot + dbeta, dgamma_tot + dgamma
+        grads[pre + ".1.gamma"] = np.asarray(dgamma_tot).astype(np.float32)
+        grads[pre + ".1.beta"] = np.asarray(dbeta_tot).astype(np.float32)
         w = self.p[pre + ".0.weight"]
         grads[pre + ".0.weight"] = conv_bwd_weight(dz, t["x"], t["k"], t["s"], t["k"] // 2)
         if t["x"].shape[1] == 3:

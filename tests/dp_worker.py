@@ -1,0 +1,128 @@
+"""Rank program of tests/test_gpu_multirank.py (not a test module): the data-parallel PRODUCT path —
+Trainer's parameter broadcast, GradBucketOverlap, SyncBatchNormHook, Trainer.step with world > 1 — under a
+real process group.  Started through videoyolo_amd.launch.spawn_ranks; all ranks share cuda:0 over gloo
+when there is one GPU (--share-gpu), or own a GPU each over RCCL (--backend nccl).
+
+    python tests/dp_worker.py OUTDIR [--backend gloo] [--share-gpu] [--size 64] [--per-rank 2] [--classes 3]
+
+Every rank writes OUTDIR/rank<r>.npz; the parent test compares the ranks with each other and with the
+oracle's data-parallel mode.
+"""
+import argparse
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+WATCH = ["stages.0.0.0.weight", "stages.0.1.1.gamma", "stages.0.2.body.0.1.beta", "stages.1.0.0.weight",
+         "stages.2.0.1.gamma", "yolo_blocks.0.body.0.0.weight", "yolo_blocks.2.tip.1.beta",
+         "transitions.1.0.weight", "yolo_outputs.1.prediction.bias", "yolo_outputs.2.prediction.weight"]
+RUNNING = ["stages.0.0.1.running_mean", "stages.0.1.1.running_var", "stages.0.2.body.0.1.running_mean",
+           "stages.1.0.1.running_mean", "yolo_blocks.1.body.2.1.running_var"]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("outdir")
+    ap.add_argument("--backend", default="gloo")
+    ap.add_argument("--share-gpu", action="store_true")
+    ap.add_argument("--size", type=int, default=64)
+    ap.add_argument("--per-rank", type=int, default=2)
+    ap.add_argument("--classes", type=int, default=3)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import videoyolo_amd as vy
+    from videoyolo_amd import _lib, autograd, init, parallel
+    from conftest import frames
+    from oracle import targets_oracle as T  # inputs only (synthetic gt + targets); the parent does the checking
+
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    local = 0 if args.share_gpu else int(os.environ["LOCAL_RANK"])
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    kw = {"device_id": dev} if args.backend == "nccl" else {}
+    dist.init_process_group(args.backend, rank=rank, world_size=world, **kw)
+
+    C, S, pb = args.classes, args.size, args.per_rank
+    B = pb * world
+    x = frames(B, S, seed=8)
+    gt_boxes, gt_ids = T.synthetic_gt(B, S, C, m=3, seed=4, pad_to=4)
+    tg = T.prefetch_targets(C, S, S, gt_boxes, gt_ids)
+    sl = slice(rank * pb, (rank + 1) * pb)
+    mine = [x[sl], gt_boxes[sl]] + [t[sl] for t in tg]
+    out = {}
+
+    def make_net():
+        net = vy.yolo3_darknet53(["c%d" % i for i in range(C)], pretrained_base=False)
+        # every rank draws DIFFERENT weights (as an unseeded net.initialize() would): rank 0's must win
+        net.initialize(init="synthetic", seed=17 + 100 * rank)
+        net.collect_params().reset_ctx(dev)
+        return net
+
+    def fwd_bwd(net):
+        with autograd.record():
+            losses = net(*mine)
+            autograd.backward([losses[0] + losses[1] + losses[2] + losses[3]])
+        return np.stack([l.cpu().numpy() for l in losses])
+
+    # ---- A. parameter broadcast + bucketed overlapped all-reduce == plain all-reduce, per-device BatchNorm
+    net = make_net()
+    before = net.collect_params()["stages.1.3.body.0.0.weight"].data()
+    trainer = vy.Trainer(net.collect_params(), 'sgd', {'learning_rate': 1e-3, 'wd': 5e-4, 'momentum': 0.9})
+    out["bcast_before"] = before
+    out["bcast_after"] = net.collect_params()["stages.1.3.body.0.0.weight"].data()
+    trainer.enable_overlap()
+    out["A_losses"] = fwd_bwd(net)
+    trainer.allreduce_grads()
+    torch.cuda.synchronize()
+    g_overlap = net._grads.clone()
+    out["A_buckets"] = np.array(trainer._overlap.launched, np.int64)
+    trainer.disable_overlap()
+    fwd_bwd(net)
+    trainer.allreduce_grads()
+    torch.cuda.synchronize()
+    out["A_overlap_equals_plain"] = np.array(torch.equal(g_overlap, net._grads))
+    out["A_grad_absmax"] = np.array(float(g_overlap.abs().max()))
+    for n in WATCH:
+        out["A_grad/" + n] = net.grad(n)
+    for n in RUNNING:
+        out["A_running/" + n] = net.collect_params()[n].data()
+    del net, trainer, g_overlap
+
+    # ---- B. SyncBatchNorm + one full Trainer.step
+    net = make_net()
+    trainer = vy.Trainer(net.collect_params(), 'sgd', {'learning_rate': 1e-3, 'wd': 5e-4, 'momentum': 0.9})
+    trainer.enable_overlap()
+    hook = parallel.SyncBatchNormHook(net)
+    out["B_losses"] = fwd_bwd(net)
+    trainer.allreduce_grads()
+    for n in WATCH:
+        out["B_grad/" + n] = net.grad(n)
+    for n in RUNNING:
+        out["B_running/" + n] = net.collect_params()[n].data()
+    out["B_sync_calls"] = np.array(hook.calls, np.int64)
+    trainer.update(B)
+    for n in WATCH:
+        out["B_param/" + n] = net.collect_params()[n].data()
+    # second step through the one-call form
+    l2 = None
+    with autograd.record():
+        losses = net(*mine)
+        autograd.backward(losses)
+    trainer.step(B)
+    out["B_losses2"] = np.stack([l.cpu().numpy() for l in losses])
+    out["B_param2/stages.0.0.0.weight"] = net.collect_params()["stages.0.0.0.weight"].data()
+    torch.cuda.synchronize()
+    np.savez(os.path.join(args.outdir, "rank%d.npz" % rank), **out)
+    dist.barrier()
+    dist.destroy_process_group()
+    print("rank", rank, "done")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,156 @@
+"""-m gpu: the N > 1 product path under a real process group — 2 ranks sharing the one GPU of the test box
+over gloo (RCCL needs 2 devices; the driver's scaling run covers it).  Ranks are started the way
+`python bench.py --gpus N` starts them (videoyolo_amd/launch.py): plain child processes of a parent that
+never touches the GPU.
+
+  * Trainer broadcasts rank 0's parameters (ranks initialise with different seeds)
+  * GradBucketOverlap: gradient buffer after the bucketed, overlapped all-reduce == one all-reduce after
+    backward, bit for bit
+  * data-parallel step (per-device BatchNorm) and SyncBatchNorm step against the oracle's data-parallel mode:
+    losses 1e-4, gradients 2e-3 of each tensor's max, running statistics per device
+  * after Trainer.step all ranks hold identical weights
+  * bench.py --gpus 2 (both modes) prints a line with n_gpus == 2
+"""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import frames
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+WORLD = 2
+# (classes, size, frames per rank): a small case, and BASELINE configs[4]'s shape — SyncBN training at 608 x 608,
+# VOC classes — at 2 ranks x 2 frames
+CASES = {"small": (3, 64, 2), "configs4_608": (20, 608, 2)}
+
+
+@pytest.fixture(scope="module", params=list(CASES))
+def case(request):
+    return CASES[request.param]
+
+
+@pytest.fixture(scope="module")
+def ranks(case, tmp_path_factory):
+    from videoyolo_amd import launch
+    C, S, PB = case
+    out = tmp_path_factory.mktemp("dp")
+    rc = launch.spawn_ranks(WORLD, [os.path.join(ROOT, "tests", "dp_worker.py"), str(out), "--backend", "gloo",
+                                    "--share-gpu", "--size", str(S), "--per-rank", str(PB), "--classes", str(C)],
+                            timeout=1500)
+    assert rc == 0, "a rank failed (exit code %d)" % rc
+    return [dict(np.load(str(out / ("rank%d.npz" % r)))) for r in range(WORLD)]
+
+
+@pytest.fixture(scope="module")
+def problem(case):
+    from videoyolo_amd import init
+    from oracle import targets_oracle as T
+    from oracle import yolo3_oracle as O
+    C, S, PB = case
+    params = init.synthetic_params(O.param_shapes(C), seed=17)      # rank 0's draw
+    B = PB * WORLD
+    x = frames(B, S, seed=8)
+    gt_boxes, gt_ids = T.synthetic_gt(B, S, C, m=3, seed=4, pad_to=4)
+    tg = T.prefetch_targets(C, S, S, gt_boxes, gt_ids)
+    return params, x, gt_boxes, tg, (C, S, PB)
+
+
+def test_parameters_are_broadcast_from_rank0(ranks, problem):
+    params = problem[0]
+    name = "stages.1.3.body.0.0.weight"
+    assert np.array_equal(ranks[0]["bcast_before"], params[name])
+    assert not np.array_equal(ranks[1]["bcast_before"], params[name])     # rank 1 drew other weights
+    for r in ranks:
+        assert np.array_equal(r["bcast_after"], params[name])
+
+
+def test_bucketed_overlap_equals_plain_allreduce(ranks):
+    for r in ranks:
+        assert bool(r["A_overlap_equals_plain"])
+        assert float(r["A_grad_absmax"]) > 0
+        b = r["A_buckets"]
+        assert b.shape == (4, 2)                                          # heads, stages.2, stages.1, stages.0
+        assert (np.diff(b[:, 0]) < 0).all()                               # deep -> shallow: descending offsets
+        assert b[:, 1].sum() >= 61626049                                  # the buckets cover every trainable tensor
+
+
+def _check_against_oracle(ranks, problem, phase, sync_bn):
+    from oracle import yolo3_train_oracle as TO
+    params, x, gt_boxes, tg, (C, S, PB) = problem
+    slices = [slice(r * PB, (r + 1) * PB) for r in range(WORLD)]
+    orc = TO.OracleYolo3Train(C, dict(params), device_slices=slices, sync_bn=sync_bn)
+    ref_losses = np.stack(orc.forward_train(x, gt_boxes, *tg))          # (4, B)
+    ref_grads = orc.backward()
+    for r, sl in enumerate(slices):
+        np.testing.assert_allclose(ranks[r][phase + "_losses"], ref_losses[:, sl], rtol=1e-4, atol=1e-4)
+        for key in ranks[r]:
+            if key.startswith(phase + "_grad/"):
+                name = key.split("/", 1)[1]
+                want = ref_grads[name]
+                err = np.abs(ranks[r][key] - want).max() / (np.abs(want).max() + 1e-6)
+                assert err < 2e-3, (name, err)
+            if key.startswith(phase + "_running/"):
+                name = key.split("/", 1)[1]
+                np.testing.assert_allclose(ranks[r][key], orc.new_running_dev[r][name], rtol=1e-4, atol=1e-5)
+    return orc, ref_grads
+
+
+def test_data_parallel_step_matches_the_oracle(ranks, problem):
+    if problem[4][1] > 96:
+        pytest.skip("full-size case: the SyncBN step below is the configs[4] check (one oracle run)")
+    _check_against_oracle(ranks, problem, "A", sync_bn=False)
+    # all-reduced gradients are the same bits on every rank
+    for key in ranks[0]:
+        if key.startswith("A_grad/"):
+            assert np.array_equal(ranks[0][key], ranks[1][key]), key
+    # per-device BatchNorm: the ranks' running statistics differ
+    assert not np.array_equal(ranks[0]["A_running/stages.0.1.1.running_var"], ranks[1]["A_running/stages.0.1.1.running_var"])
+
+
+def test_syncbn_step_matches_the_oracle(ranks, problem):
+    from oracle import yolo3_train_oracle as TO
+    params, (C, S, PB) = problem[0], problem[4]
+    orc, ref_grads = _check_against_oracle(ranks, problem, "B", sync_bn=True)
+    for r in ranks:
+        calls = r["B_sync_calls"]
+        # one exchange of [2][C] doubles per SyncBatchNorm layer and direction: stem 32 .. stages.2.0 1024; 2 steps
+        assert len(calls) == 24 and sorted(set(calls.tolist())) == [64, 128, 256, 512, 1024, 2048]
+    # synchronised layers share their running statistics, per-device layers do not
+    assert np.array_equal(ranks[0]["B_running/stages.0.1.1.running_var"], ranks[1]["B_running/stages.0.1.1.running_var"])
+    assert np.array_equal(ranks[0]["B_running/stages.1.0.1.running_mean"], ranks[1]["B_running/stages.1.0.1.running_mean"])
+    assert not np.array_equal(ranks[0]["B_running/stages.0.2.body.0.1.running_mean"],
+                              ranks[1]["B_running/stages.0.2.body.0.1.running_mean"])
+    # Trainer.update(global batch): every rank applies the same update to the same weights
+    B = PB * WORLD
+    p_ref = {k: v.copy() for k, v in params.items()}
+    TO.sgd_step(p_ref, ref_grads, {}, 1e-3, 0.9, 5e-4, B)
+    for key in ranks[0]:
+        if key.startswith("B_param/"):
+            name = key.split("/", 1)[1]
+            assert np.array_equal(ranks[0][key], ranks[1][key]), name
+            atol = 2e-6 + 2e-3 * 1e-3 * float(np.abs(ref_grads[name]).max()) / B
+            np.testing.assert_allclose(ranks[0][key], p_ref[name], rtol=0, atol=atol)
+            assert np.abs(ranks[0][key] - params[name]).max() > 0
+    assert np.array_equal(ranks[0]["B_param2/stages.0.0.0.weight"], ranks[1]["B_param2/stages.0.0.0.weight"])
+    assert np.isfinite(ranks[0]["B_losses2"]).all()
+
+
+@pytest.mark.parametrize("extra", [[], ["--mode", "train"], ["--mode", "train", "--syncbn"]])
+def test_bench_starts_its_own_ranks(extra):
+    """`python bench.py --gpus 2` without a rank environment: the parent spawns the ranks itself."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--share-gpu",
+           "--size", "96", "--batch", "2", "--steps", "2", "--warmup", "1", "--cpu-frames", "0"] + extra
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    lines = [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout.decode()
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["config"]["global_batch"] == 4 and r["value"] > 0
+    assert r["scaling"] == "weak" and r["steps"] == 2

@@ -277,10 +277,14 @@ def test_api_surface_on_device(voc_classes, synth20, tmp_path):
     other.load_parameters(path)
     assert all(torch.equal(p, q) for p, q in zip(ra, other(xa, return_index=True)))
 
-    with autograd.train_mode():                        # train-mode non-recording call (yolo3.py:1189-1192)
-        out = net(np.zeros((1, 3, 96, 96), np.float32))
-    assert len(out) == 8 and out[1][0].shape == (1, 1, 3, 2)
-    assert all(torch.equal(p, q) for p, q in zip(ra, net(xa, return_index=True)))      # inference unaffected
+    # train-mode non-recording call on a deep copy, as the DataLoader transform does (transforms.py:190-193);
+    # values: tests/test_gpu_train_parity.py::test_train_mode_without_recording
+    fake = copy.deepcopy(net)
+    fake.collect_params().reset_ctx("cuda:0")
+    with autograd.train_mode():
+        out = fake(np.zeros((1, 3, 96, 96), np.float32))
+    assert len(out) == 8 and out[1][0].shape == (1, 1, 3, 2) and out[0].shape == (1, 3 * (9 + 36 + 144), 4)
+    assert all(torch.equal(p, q) for p, q in zip(ra, net(xa, return_index=True)))      # the net itself is unaffected
 
 
 def test_nms_disabled_returns_the_detection_tensor(voc_classes, synth20):
@@ -297,6 +301,40 @@ def test_nms_disabled_returns_the_detection_tensor(voc_classes, synth20):
     assert np.array_equal(keep, np.broadcast_to(np.arange(n, dtype=np.int32), (2, n)))
     net.set_nms(0.45, 400, 100)                       # and back: the usual 100 rows
     assert net(x)[0].shape == (2, 100, 1)
+
+
+@pytest.mark.parametrize("size,post,obj_bias", [(96, 100, 0.0), (96, 700, 0.0), (224, 300, 0.0), (96, 100, -3.5)])
+def test_nms_topk_disabled_uses_every_valid_candidate(voc_classes, size, post, obj_bias):
+    """set_nms(nms_topk=-1) ("use -1 to disable", yolo3.py:1208-1228): box_nms sorts and suppresses ALL valid
+    candidates (11 340 per image at 96 x 96 / 20 classes, 61 740 at 224 x 224 — far beyond one 1024-entry chunk)
+    and the first post_nms survivors come back: kept rows exact against the oracle's unbounded NMS.  The
+    sparse case (objectness bias -3.5) has fewer valid candidates than one chunk."""
+    from videoyolo_amd import _lib, init
+    from oracle import yolo3_oracle as O
+    params = init.synthetic_params(O.param_shapes(20), seed=233, obj_bias=obj_bias)
+    x = frames(2, size, seed=size + post)
+    net = _net(voc_classes, params)
+    net.set_nms(0.45, -1, post)
+    ids, scores, bboxes, keep = [t.cpu().numpy() for t in net(x, return_index=True)]
+    r = _oracle(params, nms_topk=-1, post_nms=post)(x)
+    assert ids.shape == (2, post, 1)
+    assert np.array_equal(keep, r[3]) and np.array_equal(ids, r[0])
+    np.testing.assert_allclose(scores, r[1], rtol=0, atol=TOL)
+    fin = np.isfinite(r[2])
+    np.testing.assert_allclose(bboxes[fin], r[2][fin], rtol=0, atol=TOL)
+    assert (keep >= 0).sum() > 10
+    # and it differs from the top-400 result whenever the 400 best do not already give `post` survivors
+    net.set_nms(0.45, 400, post)
+    k400 = net(x, return_index=True)[3].cpu().numpy()
+    if (k400 >= 0).sum() < (keep >= 0).sum():
+        assert np.array_equal(k400[k400 >= 0], keep[:, :k400.shape[1]][k400 >= 0])   # a prefix of the unbounded run
+    # combinations without a bounded output are refused, loudly
+    net.set_nms(0.45, -1, -1)
+    with pytest.raises(_lib.VyError):
+        net(x)
+    net.set_nms(0.45, 2000, 100)
+    with pytest.raises(_lib.VyError):
+        net(x)
 
 
 def test_denormal_range_is_kept():

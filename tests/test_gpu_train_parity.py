@@ -118,6 +118,65 @@ def test_train_options_and_inference_after_training():
     assert np.array_equal(keep, r[3]) and np.array_equal(ids, r[0])
 
 
+@pytest.mark.parametrize("C,B,S", [(4, 2, 64), (20, 3, 96)])
+def test_train_mode_without_recording(C, B, S):
+    """net(x) under autograd.train_mode() without record(): the 8-tuple of yolo3.py:1189-1192 with real
+    values — decoded boxes and raw centre / scale / objectness / class predictions of a forward on batch
+    statistics — against the oracle's train-mode forward; anchors / offsets / fake feature maps as the
+    prefetch target generator consumes them (transforms.py:190-197); running statistics move as in any
+    is_training BatchNorm forward."""
+    from videoyolo_amd import autograd
+    from oracle import targets_oracle as T
+    from oracle import yolo3_train_oracle as TO
+    params, x, _, _ = _setup(C, B, S)
+    orc = TO.OracleYolo3Train(C, dict(params))
+    want = orc.split_preds(orc.forward_raw(x))
+    net = _net(C, params)
+    with autograd.train_mode():
+        out = net(x)
+    assert len(out) == 8
+    box, anchors, offsets, fms, ctr, scl, obj, cls = out
+    for got, key in ((ctr, "xy"), (scl, "wh"), (obj, "obj"), (cls, "cls")):
+        got = got.cpu().numpy()
+        assert got.shape == want[key].shape
+        assert np.array_equal(got, want[key]), key       # raw predictions: the conv stack is order-reproducible
+    box = box.cpu().numpy()
+    fin = np.isfinite(want["box"])
+    np.testing.assert_allclose(box[fin], want["box"][fin], rtol=0, atol=1e-4)
+    r_anchors, r_offsets, r_fms = T.anchors_offsets_featmaps(S, S)
+    for i in range(3):
+        assert np.array_equal(anchors[i], r_anchors[i]) and np.array_equal(offsets[i], r_offsets[i])
+        assert fms[i].shape == (1, 1) + tuple(r_fms[i])
+    for name, w in orc.new_running.items():
+        np.testing.assert_allclose(net.collect_params()[name].data(), w, rtol=1e-4, atol=1e-5)
+    with pytest.raises(RuntimeError):
+        autograd.backward([])                                # nothing was recorded
+    # the recorded call still works on the same object afterwards
+    gt_boxes, tg = _setup(C, B, S)[2:]
+    with autograd.record():
+        losses = net(x, gt_boxes, *tg)
+        autograd.backward(losses)
+    assert all(np.isfinite(l.cpu().numpy()).all() for l in losses)
+
+
+def test_backward_rejects_heads_that_are_not_the_sum_of_the_four_losses():
+    """autograd.backward(obj + center + scale + cls) is the one pattern the reference uses (train_yolov3.py:626-631);
+    a subset or a scaled loss must raise instead of silently back-propagating the full sum."""
+    from videoyolo_amd import autograd
+    C, B, S = 3, 2, 64
+    params, x, gt_boxes, tg = _setup(C, B, S)
+    net = _net(C, params)
+    with autograd.record():
+        losses = net(x, gt_boxes, *tg)
+        with pytest.raises(NotImplementedError):
+            autograd.backward([losses[0]])
+        with pytest.raises(NotImplementedError):
+            autograd.backward([losses[0] * 2 + losses[1] + losses[2] + losses[3]])
+        autograd.backward([losses[0] + losses[1] + losses[2] + losses[3]])   # still pending: now it runs
+    net.collect_params().zero_grad()
+    assert float(np.abs(net.grad("stages.0.0.0.weight")).max()) == 0.0
+
+
 def test_syncbn_plumbing_with_simulated_ranks():
     """SyncBatchNorm path on one GPU: the statistics callback is driven with a stand-in for the RCCL
     all-reduce that doubles the [2][C] sums, i.e. two ranks holding the same frames.  Batch mean and

@@ -14,16 +14,22 @@ from test_oracle_vs_torch import TorchYolo3
 
 
 class TorchYolo3Train(TorchYolo3):
-    def __init__(self, ncls, p, branch=None):
+    def __init__(self, ncls, p, branch=None, device_slices=None, sync_bn=False):
         super().__init__(ncls, p)
         self.branch = branch
+        self.device_slices, self.sync_bn = device_slices, sync_bn
         self.p = {k: v.clone().double().requires_grad_(not k.endswith(("running_mean", "running_var")))
                   for k, v in self.p.items()}
 
     def cell(self, x, pre, k, s):
         p = self.p
         x = F.conv2d(x, p[pre + ".0.weight"], None, s, k // 2)
-        x = F.batch_norm(x, None, None, p[pre + ".1.gamma"], p[pre + ".1.beta"], True, 0.1, 1e-5)
+        bn = lambda t: F.batch_norm(t, None, None, p[pre + ".1.gamma"], p[pre + ".1.beta"], True, 0.1, 1e-5)
+        synced = self.sync_bn and pre.startswith("stages.") and ".body." not in pre
+        if self.device_slices and not synced:   # data parallel: each device normalises its own slice
+            x = torch.cat([bn(x[sl]) for sl in self.device_slices], 0)
+        else:
+            x = bn(x)
         if self.branch is not None:
             # LeakyReLU is piecewise linear; with a handful of positive anchors a single element whose
             # pre-activation is within fp32-vs-fp64 drift of 0 changes small-layer gradients by
@@ -136,3 +142,36 @@ def test_running_stats_update(setup):
                                0.9 * params[pre + ".1.running_mean"] + 0.1 * m, atol=1e-6)
     np.testing.assert_allclose(orc.new_running[pre + ".1.running_var"],
                                0.9 * params[pre + ".1.running_var"] + 0.1 * v, atol=1e-6)
+
+
+@pytest.mark.parametrize("sync_bn", [False, True])
+def test_data_parallel_oracle_agrees_with_torch_autograd(sync_bn):
+    """The oracle's data-parallel mode (one BatchNorm statistics group per device slice; with SyncBatchNorm the
+    stem and the five stride-2 convs use the whole batch; gradients summed over devices) against the
+    same structure written with torch ops and differentiated by torch.autograd."""
+    from videoyolo_amd import init
+    C, B, S = 3, 4, 64
+    params = init.synthetic_params(O.param_shapes(C), seed=17)
+    x = frames(B, S, seed=8)
+    gt_boxes, gt_ids = T.synthetic_gt(B, S, C, m=3, seed=4, pad_to=4)
+    tg = T.prefetch_targets(C, S, S, gt_boxes, gt_ids)
+    slices = [slice(0, 2), slice(2, 4)]
+    orc = TO.OracleYolo3Train(C, params, device_slices=slices, sync_bn=sync_bn)
+    losses = orc.forward_train(x, gt_boxes, *tg)
+    grads = orc.backward()
+    branch = {t["pre"]: t["out"] > 0 for t in orc.tape if t.get("kind") == "cell"}
+    tm = TorchYolo3Train(C, params, branch, device_slices=slices, sync_bn=sync_bn)
+    tl = tm.losses(x, gt_boxes, *tg)
+    for a, b in zip(losses, tl):
+        np.testing.assert_allclose(a, b.detach().numpy(), rtol=2e-4, atol=1e-4)
+    sum(t.sum() for t in tl).backward()
+    for k, g in grads.items():
+        ref = tm.p[k].grad.numpy()
+        assert np.abs(g - ref).max() / (np.abs(ref).max() + 1e-6) < 1e-3, k
+    # the mode really changes the numbers: a whole-batch BatchNorm run gives different losses
+    whole = TO.OracleYolo3Train(C, params).forward_train(x, gt_boxes, *tg)
+    assert not np.allclose(np.concatenate(whole), np.concatenate(losses), rtol=1e-5, atol=1e-6)
+    # running statistics: per device, except the synchronised layers
+    rm0, rm1 = orc.new_running_dev
+    assert np.array_equal(rm0["stages.0.1.1.running_mean"], rm1["stages.0.1.1.running_mean"]) == sync_bn
+    assert not np.array_equal(rm0["stages.0.2.body.0.1.running_mean"], rm1["stages.0.2.body.0.1.running_mean"])

@@ -154,3 +154,65 @@ def test_nms_agrees_with_python_reference(both):
     d[::17] = -1
     out, idx = O.box_nms(d[None], 0.45, 0.01, 100)
     assert [int(i) for i in idx[0] if i >= 0] == _py_nms(d.astype(np.float64), 0.45, 0.01, 100)
+
+
+class TorchYolo3F64(TorchYolo3):
+    """The same torch graph evaluated in float64: the closest thing to exact arithmetic available here."""
+
+    def __init__(self, ncls, p):
+        self.C, self.p = ncls, {k: _t(v).double() for k, v in p.items()}
+
+
+@pytest.mark.parametrize("size", [416, 608])
+def test_full_size_frame_agrees_with_torch_fp32_and_fp64(synth20, size, capsys):
+    """BASELINE configs[0] (1 x 416 x 416, seed 233 = train_yolov3.py:135) and one 608 x 608 frame (the
+    configs[1] shape): the oracle against the torch model in fp32 AND in float64.
+
+    Bars (north_star: ids / kept rows exact, scores and coordinates 1e-4):
+      heads   |oracle - torch| <= 1e-4 absolute (raw predictions are O(1); observed <= 2e-5)
+      scores  <= 1e-4 absolute (observed <= 4e-6)
+      boxes   <= 1e-4 x max(1, box width, box height): `exp(raw) * anchor` turns an absolute error of the raw
+              prediction into one RELATIVE to the box extent, and with random weights boxes reach 1000 px —
+              torch-fp32 and torch-float64 themselves differ by up to 5e-3 px there, so an absolute 1e-4
+              between two independently ordered fp32 evaluations does not exist; relative to the extent the
+              oracle sits at <= 3e-5
+      NMS     kept rows identical — the oracle's box_nms on its own detections, the plain-Python NMS on the
+              oracle's, on torch-fp32's and on torch-float64's detection tensors all keep the same rows
+    and the oracle must be about as close to float64 as torch's own fp32 path is (what the matrix-core
+    summation order 0,4,1,5,2,6,3,7 costs): within 4x."""
+    x = frames(1, size, seed=233)
+    orc = O.OracleYolo3(20, synth20)
+    oh = orc.raw_heads(x)
+    with torch.no_grad():
+        t32 = TorchYolo3(20, synth20)
+        th = t32.forward_heads(x)
+        th64 = TorchYolo3F64(20, synth20).forward_heads(x.astype(np.float64))
+    worst = 0.0
+    for i in range(3):
+        a, b, c = oh[i], th[i].numpy(), th64[i].numpy()
+        np.testing.assert_allclose(a, b, rtol=0, atol=1e-4)
+        np.testing.assert_allclose(a, c, rtol=0, atol=1e-4)
+        d_orc, d_t32 = np.abs(a - c).max(), np.abs(b - c).max()
+        worst = max(worst, d_orc / d_t32)
+        assert d_orc <= 4 * d_t32, (i, d_orc, d_t32)
+    with torch.no_grad():
+        td = torch.cat([t32.decode(h, i) for i, h in enumerate(th)], 1).numpy()
+        td64 = torch.cat([t32.decode(h.float(), i) for i, h in enumerate(th64)], 1).numpy()
+    od = orc.detections(x)
+    n = 3 * sum((size // s) ** 2 for s in (32, 16, 8))
+    assert od.shape == td.shape == (1, 20 * n, 6)
+    assert np.array_equal(od[..., 0], td[..., 0])                         # class ids: the reference's row order
+    for other in (td, td64):
+        np.testing.assert_allclose(od[..., 1], other[..., 1], rtol=0, atol=1e-4)
+        fin = np.isfinite(other[..., 2:]).all(-1) & np.isfinite(od[..., 2:]).all(-1)
+        assert fin.mean() > 0.999
+        ext = np.maximum(1.0, np.maximum(other[..., 4] - other[..., 2], other[..., 5] - other[..., 3]))[fin]
+        err = np.abs(od[..., 2:] - other[..., 2:])[fin].max(-1)
+        assert (err <= 1e-4 * ext).all(), float((err / ext).max())
+    ids, scores, bboxes, idx = orc.nms(od)
+    got = [int(i) for i in idx[0] if i >= 0]
+    assert len(got) == 100
+    for det in (od, td, td64):
+        assert got == _py_nms(det[0].astype(np.float64), 0.45, 0.01, 400)[:100]
+    with capsys.disabled():
+        print("\n[%d] oracle-vs-float64 / torch32-vs-float64 head distance ratio: %.2f" % (size, worst))

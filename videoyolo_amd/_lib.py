@@ -66,6 +66,7 @@ SIGNATURES.update({
     "vy_net_bind_train": (ctypes.c_int, [_vp, _vp, _sz, _i32, _i32, _i32, _vp, _vp, _vp]),
     "vy_net_set_train_options": (ctypes.c_int, [_vp, _f32, _i32]),
     "vy_net_train_forward": (ctypes.c_int, [_vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "vy_net_train_mode_forward": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "vy_net_train_backward": (ctypes.c_int, [_vp, _vp, _vp]),
     "vy_net_param_set_opt": (ctypes.c_int, [_vp, _i32, _f32, _f32, _i32]),
     "vy_net_sgd_step": (ctypes.c_int, [_vp, _f32, _f32, _f32, _f32, _vp]),

@@ -63,15 +63,72 @@ def _register(net):
         s.tape.append(net)
 
 
+_loss_cls = None
+
+
+def loss_vector(tensor, net, index):
+    """Wrap one of a net's four (B,) loss vectors so that ``backward`` can tell what its heads are made
+    of: a torch.Tensor subclass whose ``terms`` ({(id(net), loss index): multiplicity}) survive ``+``
+    (``obj + center + scale + cls``, ``sum([...])``) and nothing else — any other operation returns a
+    plain tensor."""
+    global _loss_cls
+    if _loss_cls is None:
+        import collections
+        import torch
+
+        class LossVector(torch.Tensor):
+            terms = None
+
+            @classmethod
+            def __torch_function__(cls, func, types, args=(), kwargs=None):
+                with torch._C.DisableTorchFunctionSubclass():
+                    out = func(*args, **(kwargs or {}))
+                if not isinstance(out, torch.Tensor):
+                    return out
+                out = out.as_subclass(torch.Tensor)
+                if func in (torch.add, torch.Tensor.add, torch.Tensor.__add__, torch.Tensor.__radd__) and not kwargs:
+                    terms = collections.Counter()
+                    for a in args:
+                        if isinstance(a, LossVector) and a.terms is not None:
+                            terms.update(a.terms)
+                        elif not (isinstance(a, (int, float)) and a == 0):
+                            return out
+                    out = out.as_subclass(LossVector)
+                    out.terms = terms
+                return out
+        _loss_cls = LossVector
+    import collections
+    out = tensor.as_subclass(_loss_cls)
+    out.terms = collections.Counter({(id(net), index): 1})
+    return out
+
+
 def backward(heads, head_grads=None, retain_graph=False, train_mode=True):
-    """``autograd.backward(sum_losses)`` (train_yolov3.py:631).  The only pattern the reference uses —
-    unit head gradients on the sum of the four loss vectors of each net — is what the recorded
-    forward already prepared; this walks every pending net's backward pass."""
+    """``autograd.backward(sum_losses)`` (train_yolov3.py:626-631).  The one pattern the reference uses —
+    unit head gradients on ``obj_loss + center_loss + scale_loss + cls_loss`` of each net — is what the
+    recorded forward already prepared (d(sum of the four)/d(raw predictions)); this checks that `heads` IS
+    that sum for every pending net and walks their backward passes.  Anything else (a subset of the
+    losses, scaled losses, head_grads) raises instead of silently back-propagating the full sum."""
     if head_grads is not None:
         raise NotImplementedError("non-unit head gradients are not part of the reference's call pattern")
     s = _get()
-    tape, s.tape = getattr(s, "tape", []), []
+    tape = getattr(s, "tape", [])
     if not tape:
         raise RuntimeError("autograd.backward() without a recorded forward")
+    import collections
+    got = collections.Counter()
+    for h in (heads if isinstance(heads, (list, tuple)) else [heads]):
+        terms = getattr(h, "terms", None)
+        if terms is None:
+            raise NotImplementedError(
+                "autograd.backward: a head is not a sum of a net's loss vectors (built with anything but '+'); "
+                "only backward(obj_loss + center_loss + scale_loss + cls_loss) is supported")
+        got.update(terms)
+    want = collections.Counter({(id(net), i): 1 for net in tape for i in range(4)})
+    if got != want:
+        raise NotImplementedError(
+            "autograd.backward: heads must be exactly obj_loss + center_loss + scale_loss + cls_loss of every "
+            "recorded net (train_yolov3.py:626); got loss indices %s" % sorted(i for (_, i), _ in got.items()))
+    s.tape = []
     for net in tape:
         net.backward()

@@ -396,6 +396,233 @@ __global__ __launch_bounds__(kNmsThreads) void sort_nms_kernel(const DetArgs d, 
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// nms_topk <= 0 ("use -1 to disable so that every detection is used for NMS", yolo3.py:1208-1228): box_nms then
+// sorts EVERY valid candidate (up to N*C per image) and suppresses greedily; the caller keeps the first
+// post_nms survivors.  A survivor only depends on the survivors before it, so the sorted list can be consumed
+// in chunks: one workgroup per image repeatedly (1) radix-selects the next <= 1024 largest keys below the
+// previous chunk's threshold from the cached class scores, (2) decodes and bitonic-sorts them, (3) suppresses
+// them against the rows kept so far and among themselves, (4) appends the survivors to the output — until
+// post_nms rows are kept or the valid candidates are exhausted.  Typical inputs finish in one or two chunks; the
+// worst case (everything suppressed) walks all N*C candidates, like the reference's unbounded O(n^2) loop.
+constexpr int kAllThreads = 1024;
+
+__global__ __launch_bounds__(kAllThreads) void nms_all_kernel(const DetArgs d, void* scratch, int n_items, int rows,
+                                                              float* ids, float* scores, float* bboxes,
+                                                              int32_t* keep_idx) {
+  const int b = blockIdx.x, t = threadIdx.x;
+  Scratch sc = carve(scratch, d.B);
+  const float* cache = sc.score + (size_t)b * d.C * n_items;
+  __shared__ uint32_t hist[kBins];
+  __shared__ unsigned long long key[VY_NMS_MAX_TOPK];
+  __shared__ uint16_t perm[VY_NMS_MAX_TOPK];
+  __shared__ float bx1[VY_NMS_MAX_TOPK], by1[VY_NMS_MAX_TOPK], bx2[VY_NMS_MAX_TOPK], by2[VY_NMS_MAX_TOPK];
+  __shared__ float bcls[VY_NMS_MAX_TOPK];
+  __shared__ uint8_t alive[VY_NMS_MAX_TOPK];
+  __shared__ int pos[VY_NMS_MAX_TOPK];
+  __shared__ float kx1[VY_NMS_MAX_TOPK], ky1[VY_NMS_MAX_TOPK], kx2[VY_NMS_MAX_TOPK], ky2[VY_NMS_MAX_TOPK];
+  __shared__ float kcls[VY_NMS_MAX_TOPK];
+  __shared__ SelState st;
+  __shared__ int n_kept, n_taken;
+  const int n0 = d.head[0].H * d.head[0].W * 3, n1 = d.head[1].H * d.head[1].W * 3;
+  const int total = d.C * n_items;
+  // candidate row of cached score idx = c*n_items + item
+  auto cand_of = [&](int idx, int& c, int& it) -> uint32_t {
+    c = idx / n_items;
+    it = idx - c * n_items;
+    if (it < n0) return (uint32_t)(d.head[0].cand_base + c * n0 + it);
+    if (it < n0 + n1) return (uint32_t)(d.head[1].cand_base + c * n1 + (it - n0));
+    const int n2 = n_items - n0 - n1;
+    return (uint32_t)(d.head[2].cand_base + c * n2 + (it - n0 - n1));
+  };
+  if (t == 0) n_kept = 0;
+  // exclusive upper bound on the key of the candidates still to be consumed (none yet)
+  uint32_t bound_s = 0xffffffffu, bound_i = 0xffffffffu;
+  bool first = true;
+  __syncthreads();
+  while (true) {
+    if (t == 0) {
+      st.Tb = st.Ts = st.smask = st.Ti = st.imask = 0;
+      st.k_rem = st.k_eff = st.done = st.count = 0;
+      n_taken = 0;
+    }
+    __syncthreads();
+    // ---- radix select of the min(1024, remaining)-th largest remaining key
+    for (int pass = 0; pass < 7; ++pass) {
+      if (st.done) break;  // uniform: st is only written between barriers
+      hist[t] = 0;
+      __syncthreads();
+      for (int idx = t; idx < total; idx += kAllThreads) {
+        const float s = cache[idx];
+        if (!(s > d.valid_thresh)) continue;
+        int c, it;
+        const uint32_t sbits = vy_f32_to_bits(s);
+        const uint32_t inv = ((1u << kIdxBits) - 1u) - cand_of(idx, c, it);
+        if (!first && !(sbits < bound_s || (sbits == bound_s && inv < bound_i))) continue;
+        const uint32_t bucket = score_bucket(s);
+        if (!prefix_match(st, pass, bucket, sbits, inv)) continue;
+        atomicAdd(&hist[pass_digit(pass, bucket, sbits, inv)], 1u);
+      }
+      __syncthreads();
+      const uint32_t mine = hist[t];
+      pos[t] = (int)mine;  // suffix sums in pos[]
+      __syncthreads();
+      for (int off = 1; off < kBins; off <<= 1) {
+        const int add = (t + off < kBins) ? pos[t + off] : 0;
+        __syncthreads();
+        pos[t] += add;
+        __syncthreads();
+      }
+      if (t == 0 && pass == 0) {
+        const int nvalid = pos[0];
+        st.k_eff = nvalid < VY_NMS_MAX_TOPK ? nvalid : VY_NMS_MAX_TOPK;
+        st.k_rem = st.k_eff;
+        if (st.k_eff == 0) st.done = 1;
+      }
+      __syncthreads();
+      const int k_rem = st.k_rem;
+      const uint32_t above = (t + 1 < kBins) ? (uint32_t)pos[t + 1] : 0u;
+      __syncthreads();
+      if (k_rem > 0 && above < (uint32_t)k_rem && (uint32_t)k_rem <= above + mine) {
+        const int rem = k_rem - (int)above;
+        st.k_rem = rem;
+        const uint32_t dgt = (uint32_t)t;
+        switch (pass) {
+          case 0: st.Tb = dgt; break;
+          case 1: st.Ts |= dgt << 20; st.smask |= 1023u << 20; break;
+          case 2: st.Ts |= dgt << 10; st.smask |= 1023u << 10; break;
+          case 3: st.Ts |= dgt; st.smask |= 1023u; break;
+          case 4: st.Ti |= dgt << 20; st.imask |= 1023u << 20; break;
+          case 5: st.Ti |= dgt << 10; st.imask |= 1023u << 10; break;
+          default: st.Ti |= dgt; st.imask |= 1023u; break;
+        }
+        if ((uint32_t)rem == mine || pass == 6) st.done = 1;
+      }
+      __syncthreads();
+    }
+    const int k = st.k_eff;
+    if (k == 0) break;  // no valid candidate left
+    // ---- collect + decode the chunk
+    for (int idx = t; idx < total; idx += kAllThreads) {
+      const float s = cache[idx];
+      if (!(s > d.valid_thresh)) continue;
+      int c, it;
+      const uint32_t sbits = vy_f32_to_bits(s);
+      const uint32_t inv = ((1u << kIdxBits) - 1u) - cand_of(idx, c, it);
+      if (!first && !(sbits < bound_s || (sbits == bound_s && inv < bound_i))) continue;
+      const uint32_t bucket = score_bucket(s);
+      const bool take = bucket > st.Tb || (bucket == st.Tb && (sbits > st.Ts || (sbits == st.Ts && inv >= st.Ti)));
+      if (!take) continue;
+      const int slot = atomicAdd(&n_taken, 1);
+      if (slot >= VY_NMS_MAX_TOPK) continue;  // cannot happen: the threshold is exact
+      Item im;
+      locate(d, b, it, im);
+      decode_box(d, im, bx1[slot], by1[slot], bx2[slot], by2[slot]);
+      bcls[slot] = (float)c;
+      key[slot] = ((unsigned long long)sbits << 32) | inv;
+      perm[slot] = (uint16_t)slot;
+    }
+    __syncthreads();
+    int kp = 1;
+    while (kp < k) kp <<= 1;
+    for (int i = k + t; i < kp; i += kAllThreads) {
+      key[i] = 0ull;
+      perm[i] = 0;
+    }
+    __syncthreads();
+    for (int size = 2; size <= kp; size <<= 1) {
+      for (int stride = size >> 1; stride > 0; stride >>= 1) {
+        for (int i = t; i < (kp >> 1); i += kAllThreads) {
+          const int lo = ((i / stride) * (stride << 1)) + (i % stride);
+          const int hi = lo + stride;
+          const bool desc = ((lo & size) == 0);
+          const unsigned long long a = key[lo], c = key[hi];
+          if ((a < c) == desc) {
+            key[lo] = c;
+            key[hi] = a;
+            const uint16_t pa = perm[lo];
+            perm[lo] = perm[hi];
+            perm[hi] = pa;
+          }
+        }
+        __syncthreads();
+      }
+    }
+    // ---- suppression: first by the rows kept in earlier chunks, then greedily inside the chunk
+    const int nk = n_kept;
+    if (t < k) {
+      const int e = perm[t];
+      bool ok = true;
+      for (int j = 0; j < nk && ok; ++j)
+        if (kcls[j] == bcls[e] && vy_box_iou(kx1[j], ky1[j], kx2[j], ky2[j], bx1[e], by1[e], bx2[e], by2[e]) > d.nms_thresh)
+          ok = false;
+      alive[t] = ok ? 1 : 0;
+    }
+    __syncthreads();
+    for (int i = 0; i < k; ++i) {
+      if (!alive[i]) continue;  // uniform
+      const int ei = perm[i];
+      const float ax1 = bx1[ei], ay1 = by1[ei], ax2 = bx2[ei], ay2 = by2[ei], ac = bcls[ei];
+      for (int j = i + 1 + t; j < k; j += kAllThreads) {
+        const int ej = perm[j];
+        if (alive[j] && bcls[ej] == ac && vy_box_iou(ax1, ay1, ax2, ay2, bx1[ej], by1[ej], bx2[ej], by2[ej]) > d.nms_thresh)
+          alive[j] = 0;
+      }
+      __syncthreads();
+    }
+    // ---- append the survivors in order
+    pos[t] = (t < k && alive[t]) ? 1 : 0;
+    __syncthreads();
+    for (int off = 1; off < VY_NMS_MAX_TOPK; off <<= 1) {
+      const int v = t >= off ? pos[t - off] : 0;
+      __syncthreads();
+      pos[t] += v;
+      __syncthreads();
+    }
+    const int add = pos[VY_NMS_MAX_TOPK - 1];
+    if (t < k && alive[t]) {
+      const int r = nk + pos[t] - 1;
+      if (r < rows) {
+        const int e = perm[t];
+        kx1[r] = bx1[e];
+        ky1[r] = by1[e];
+        kx2[r] = bx2[e];
+        ky2[r] = by2[e];
+        kcls[r] = bcls[e];
+        const size_t o = (size_t)b * rows + r;
+        ids[o] = bcls[e];
+        scores[o] = vy_bits_to_f32((uint32_t)(key[t] >> 32));
+        bboxes[o * 4 + 0] = bx1[e];
+        bboxes[o * 4 + 1] = by1[e];
+        bboxes[o * 4 + 2] = bx2[e];
+        bboxes[o * 4 + 3] = by2[e];
+        if (keep_idx) keep_idx[o] = (int32_t)(((1u << kIdxBits) - 1u) - (uint32_t)(key[t] & 0xffffffffull));
+      }
+    }
+    // next chunk: everything strictly below this chunk's smallest key
+    const unsigned long long last = key[k - 1];
+    __syncthreads();
+    if (t == 0) n_kept = (nk + add < rows) ? nk + add : rows;
+    __syncthreads();
+    if (n_kept >= rows || k < VY_NMS_MAX_TOPK) break;  // enough rows, or the candidates are exhausted
+    bound_s = (uint32_t)(last >> 32);
+    bound_i = (uint32_t)(last & 0xffffffffull);
+    first = false;
+  }
+  __syncthreads();
+  for (int r = n_kept + t; r < rows; r += kAllThreads) {
+    const size_t o = (size_t)b * rows + r;
+    ids[o] = -1.0f;
+    scores[o] = -1.0f;
+    bboxes[o * 4 + 0] = -1.0f;
+    bboxes[o * 4 + 1] = -1.0f;
+    bboxes[o * 4 + 2] = -1.0f;
+    bboxes[o * 4 + 3] = -1.0f;
+    if (keep_idx) keep_idx[o] = -1;
+  }
+}
+
 // nms_thresh outside (0,1): the reference returns the un-suppressed detection tensor itself (yolo3.py:1195-1206
 // with the box_nms branch skipped): (B, N*C, 6) rows [id, score, x1, y1, x2, y2] in class-major order per scale.
 // One thread per anchor writes its C rows (its box once per class, like the reference's tile over classes).
@@ -439,7 +666,8 @@ size_t vy_det_scratch_bytes(int B, int n_items, int C) {
 
 hipError_t vy_launch_detect(const DetArgs& a, void* scratch, float* ids, float* scores, float* bboxes,
                             int32_t* keep_idx, hipStream_t s) {
-  if (a.topk <= 0 || a.topk > VY_NMS_MAX_TOPK || a.n_cand >= (1 << kIdxBits)) return hipErrorInvalidValue;
+  if (a.topk > VY_NMS_MAX_TOPK || a.n_cand >= (1 << kIdxBits)) return hipErrorInvalidValue;
+  if (a.topk <= 0 && (a.post_nms <= 0 || a.post_nms > VY_NMS_MAX_TOPK)) return hipErrorInvalidValue;
   const int rows = a.post_nms > 0 ? a.post_nms : a.topk;
   // state + histogram region back to zero (entries need no clearing)
   hipError_t e = hipMemsetAsync(scratch, 0,
@@ -451,6 +679,12 @@ hipError_t vy_launch_detect(const DetArgs& a, void* scratch, float* ids, float* 
   for (int i = 0; i < 3; ++i) n_items += a.head[i].H * a.head[i].W * 3;
   const int per_block = kHistThreads * kItemsPerThread;
   dim3 grid((n_items + per_block - 1) / per_block, a.B);
+  if (a.topk <= 0) {  // every valid candidate goes through NMS: pass 0 only fills the score cache
+    hipLaunchKernelGGL(hist_kernel, grid, dim3(kHistThreads), 0, s, a, scratch, 0, n_items);
+    hipLaunchKernelGGL(nms_all_kernel, dim3(a.B), dim3(kAllThreads), 0, s, a, scratch, n_items, rows, ids, scores,
+                       bboxes, keep_idx);
+    return hipGetLastError();
+  }
   for (int pass = 0; pass < 7; ++pass) {
     hipLaunchKernelGGL(hist_kernel, grid, dim3(kHistThreads), 0, s, a, scratch, pass, n_items);
     hipLaunchKernelGGL(select_kernel, dim3(a.B), dim3(kBins), 0, s, a, scratch, pass);

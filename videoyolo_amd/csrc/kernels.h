@@ -225,6 +225,18 @@ hipError_t vy_launch_loss(const LossArgs& a, hipStream_t s);
 hipError_t vy_launch_loss_reduce(const float* partials, int blocks_per_image, int B, float* losses,
                                  hipStream_t s);
 
+// ---- train-mode non-recording outputs (yolo3.py:1189-1192, items 0 and 4-7 of the 8-tuple)
+struct RawPredArgs {
+  HeadView head[3];
+  float* box;         // (B, N, 4) decoded corner boxes
+  float* centers;     // (B, N, 2) raw
+  float* scales;      // (B, N, 2) raw
+  float* objness;     // (B, N, 1) raw
+  float* class_pred;  // (B, N, C) raw
+  int B, C, N;
+};
+hipError_t vy_launch_raw_preds(const RawPredArgs& a, hipStream_t s);
+
 // ---- SGD with momentum (mx.optimizer.SGD via gluon.Trainer.step, train_yolov3.py:527-530,634)
 struct SgdSeg {
   int64_t off, size;      // element range in the flat parameter / gradient / momentum buffers

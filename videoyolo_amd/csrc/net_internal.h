@@ -374,8 +374,12 @@ struct vy_net {
               Hook&& hook) {
     if (int rc = check_ready()) return rc;
     const bool nms_on = nms_thresh > 0.f && nms_thresh < 1.f;  // yolo3.py:1197
-    if (nms_on && (nms_topk <= 0 || nms_topk > VY_MAX_TOPK))
-      return fail(VY_ERR_UNSUPPORTED, "nms_topk must be in [1, %d] (got %d)", VY_MAX_TOPK, nms_topk);
+    if (nms_on && nms_topk > VY_MAX_TOPK)
+      return fail(VY_ERR_UNSUPPORTED, "nms_topk must be <= %d, or <= 0 for 'every valid candidate' (got %d)",
+                  VY_MAX_TOPK, nms_topk);
+    if (nms_on && nms_topk <= 0 && (post_nms <= 0 || post_nms > VY_MAX_TOPK))
+      return fail(VY_ERR_UNSUPPORTED, "nms_topk <= 0 needs post_nms in [1, %d] (got %d): the un-sliced output of an "
+                  "unbounded NMS has N*C rows", VY_MAX_TOPK, post_nms);
     FoldDesc* fd = reinterpret_cast<FoldDesc*>(dev_ws + fold_desc_off);
     if (!fold_uploaded) {
       HIP_TRY(hipMemcpyAsync(fd, folds.data(), sizeof(FoldDesc) * folds.size(), hipMemcpyHostToDevice, s));

@@ -731,6 +731,36 @@ int vy_net_train_forward(vy_net* net, const float* x, const float* gt_boxes, int
   return 0;
 }
 
+int vy_net_train_mode_forward(vy_net* net, const float* x, float* box_preds, float* centers, float* scales,
+                              float* objness, float* class_pred, void* stream) {
+  if (!net || !x || !box_preds || !centers || !scales || !objness || !class_pred) return fail(VY_ERR_INVALID, "null argument");
+  if (int rc = net->check_ready()) return rc;
+  VyTrain* t = net->train;
+  if (!t || !t->grads || t->B != net->B || t->H != net->H || t->W != net->W)
+    return fail(VY_ERR_STATE, "training workspace not bound (vy_net_bind_train)");
+  TrainCtx c{net, t, static_cast<hipStream_t>(stream)};
+  if (int rc = forward_train(c, x)) return rc;
+  t->forward_done = false;  // nothing was recorded: no backward may follow
+  const DetArgs d = net->det_args();
+  RawPredArgs ra;
+  memset(&ra, 0, sizeof ra);
+  int N = 0;
+  for (int i = 0; i < 3; ++i) {
+    ra.head[i] = d.head[i];
+    N += 3 * d.head[i].H * d.head[i].W;
+  }
+  ra.box = box_preds;
+  ra.centers = centers;
+  ra.scales = scales;
+  ra.objness = objness;
+  ra.class_pred = class_pred;
+  ra.B = net->B;
+  ra.C = net->num_class;
+  ra.N = N;
+  HIP_TRY(vy_launch_raw_preds(ra, c.s));
+  return 0;
+}
+
 int vy_net_train_backward(vy_net* net, const float* x, void* stream) {
   if (!net || !x) return fail(VY_ERR_INVALID, "null argument");
   if (int rc = net->check_ready()) return rc;
@@ -752,10 +782,14 @@ int vy_net_param_set_opt(vy_net* net, int32_t i, float lr_mult, float wd_mult, i
   for (int p = 0; p < (int)net->params.size(); ++p) {
     if (!net->params[p].info.trainable) continue;
     if (p == i && si < (int)t->segs.size()) {
-      t->segs[si].lr_mult = lr_mult;
-      t->segs[si].wd_mult = wd_mult;
-      t->segs[si].enabled = enabled ? 1 : 0;
-      t->seg_uploaded = false;
+      SgdSeg& sg = t->segs[si];
+      const int en = enabled ? 1 : 0;
+      if (sg.lr_mult != lr_mult || sg.wd_mult != wd_mult || sg.enabled != en) {  // re-upload only on a change
+        sg.lr_mult = lr_mult;
+        sg.wd_mult = wd_mult;
+        sg.enabled = en;
+        t->seg_uploaded = false;
+      }
     }
     ++si;
   }

@@ -545,6 +545,46 @@ __global__ __launch_bounds__(kLossThreads) void loss_kernel(const LossArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Train-mode, non-recording branch (yolo3.py:1189-1192): the per-anchor tensors YOLOOutputV3 returns when
+// autograd.is_training() (yolo3.py:162-182) — decoded corner boxes and the RAW centre / scale / objectness /
+// class predictions, concatenated over the scales in the order stride 32, 16, 8 -> cell -> anchor.
+__global__ __launch_bounds__(256) void raw_preds_kernel(const RawPredArgs a) {
+  const int b = blockIdx.y;
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  if (n >= a.N) return;
+  int it = n, s = 0;
+  for (; s < 3; ++s) {
+    const int cnt = a.head[s].H * a.head[s].W * 3;
+    if (it < cnt) break;
+    it -= cnt;
+  }
+  const HeadView& hv = a.head[s];
+  const int an = it % 3, cell = it / 3;
+  const int x = cell % hv.W, y = cell / hv.W;
+  const int P = 5 + a.C;
+  const float* p = hv.pred + ((long long)(b * (hv.H + 2) + y + 1) * (hv.W + 2) + x + 1) * hv.cs + hv.co + an * P;
+  const float rx = p[0], ry = p[1], rw = p[2], rh = p[3];
+  const float cx = (vy_sigmoidf(rx) + (float)x) * hv.stride, cy = (vy_sigmoidf(ry) + (float)y) * hv.stride;
+  const float hw = vy_expf(rw) * hv.aw[an] / 2.0f, hh = vy_expf(rh) * hv.ah[an] / 2.0f;
+  const long long r = (long long)b * a.N + n;
+  a.box[r * 4 + 0] = cx - hw;
+  a.box[r * 4 + 1] = cy - hh;
+  a.box[r * 4 + 2] = cx + hw;
+  a.box[r * 4 + 3] = cy + hh;
+  a.centers[r * 2 + 0] = rx;
+  a.centers[r * 2 + 1] = ry;
+  a.scales[r * 2 + 0] = rw;
+  a.scales[r * 2 + 1] = rh;
+  a.objness[r] = p[4];
+  for (int c = 0; c < a.C; ++c) a.class_pred[r * a.C + c] = p[5 + c];
+}
+
+hipError_t vy_launch_raw_preds(const RawPredArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(raw_preds_kernel, dim3((a.N + 255) / 256, a.B), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+
 hipError_t vy_launch_loss(const LossArgs& a, hipStream_t s) {
   if (a.M < 0 || a.M > 4096) return hipErrorInvalidValue;
   hipLaunchKernelGGL(loss_kernel, dim3(vy_loss_blocks_per_image(a.N), a.B), dim3(kLossThreads),

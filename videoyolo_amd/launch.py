@@ -50,6 +50,8 @@ def spawn_ranks(n_ranks, argv=None, timeout=None, poll=0.05):
     for r in range(n_ranks):
         procs.append(subprocess.Popen([sys.executable] + argv, env=rank_env(r, n_ranks, port),
                                       stdout=None if r == 0 else subprocess.DEVNULL))
+        if os.environ.get("VY_LAUNCH_TRACE"):
+            sys.stderr.write("[launch] rank %d/%d pid %d port %d\n" % (r, n_ranks, procs[-1].pid, port))
     t0 = time.time()
     rc = 0
     live = list(procs)

@@ -82,7 +82,10 @@ class ParameterDict(OrderedDict):
             setattr(p, name, value)
 
     def zero_grad(self):
-        pass
+        """Gradients are overwritten (grad_req='write'), never accumulated, by every backward pass; the flat
+        gradient buffer is cleared anyway so that a reader sees zeros, as after gluon's zero_grad."""
+        if self._net._grads is not None:
+            self._net._grads.zero_()
 
 
 class _TargetGeneratorState:
@@ -133,6 +136,8 @@ class YOLOV3(object):
         self._mom = None         # torch float32 flat SGD momentum buffer
         self._train_x = None     # image batch of the recorded forward (stem weight gradient)
         self._cb_keep = []       # ctypes callbacks kept alive
+        self._replicas_synced = False  # parameters broadcast from rank 0 since they were last written (parallel.sync_replicas)
+        self._opts_sent = {}     # index -> (lr_mult, wd_mult, enabled) as last handed to the library
         self._device = None
         self._hybrid = False
         self._graphs = {}
@@ -220,6 +225,7 @@ class YOLOV3(object):
 
     def _set_param(self, i, value):
         p = list(self._params.values())[i]
+        self._replicas_synced = False
         if self._dev_params is None:
             self._host[p.name] = value.copy()
             return
@@ -250,6 +256,7 @@ class YOLOV3(object):
         _lib.check(self._lib.vy_net_bind_params(self._h, ctypes.c_void_p(self._dev_params.data_ptr())))
         self._host = {}
         self._ws, self._plan = None, None
+        self._grads = self._mom = None
         for i, p in enumerate(self._params.values()):
             self._set_param(i, vals[p.name])
 
@@ -400,6 +407,8 @@ class YOLOV3(object):
             p._net = self
         self._params._net = self
         self._host, self._dev_params, self._ws, self._plan, self._device = {}, None, None, None, None
+        self._grads = self._mom = None
+        self._opts_sent = {}
         for k, v in new_vals.items():
             self._params[k].set_data(v)
         if device is not None:
@@ -448,7 +457,11 @@ class YOLOV3(object):
         """Rows of the inference outputs: post_nms (or nms_topk) after box_nms; with nms_thresh outside (0,1)
         the reference returns the whole (B, N*C, 6) detection tensor (yolo3.py:1197-1202)."""
         if 0 < self.nms_thresh < 1:
-            return self.post_nms if self.post_nms > 0 else self.nms_topk
+            rows = self.post_nms if self.post_nms > 0 else self.nms_topk
+            if rows <= 0:
+                raise _lib.VyError(-4, "nms_topk <= 0 (every valid candidate) needs post_nms >= 1: the un-sliced "
+                                       "output of an unbounded NMS has N*C rows")
+            return rows
         return int(self._lib.vy_net_num_anchors(self._h)) * len(self._classes)
 
     def _as_input(self, x):
@@ -488,6 +501,9 @@ class YOLOV3(object):
         b, _, h, w = x.shape
         tg = [self._dev(t) for t in (gt_boxes, obj_t, centers_t, scales_t, weights_t, clas_t)]
         m = int(tg[0].shape[1])
+        if not self._replicas_synced:
+            from . import parallel
+            parallel.sync_replicas(self)  # data parallel: all ranks train the same model (no-op single process)
         with torch.cuda.device(self._device):
             self._ensure_plan(b, h, w, train=True)
             n = self._lib.vy_net_num_anchors(self._h)
@@ -505,7 +521,7 @@ class YOLOV3(object):
                 ctypes.c_void_p(losses.data_ptr()), self._stream()))
         self._train_x = x
         autograd._register(self)
-        return losses[0], losses[1], losses[2], losses[3]
+        return tuple(autograd.loss_vector(losses[i], self, i) for i in range(4))
 
     def backward(self):
         """autograd.backward(sum of the four losses) for this net (train_yolov3.py:631)."""
@@ -519,11 +535,13 @@ class YOLOV3(object):
 
     def forward_train_mode(self, x):
         """``autograd.train_mode()`` without recording (transforms.py:190-193): the 8-tuple of
-        yolo3.py:1189-1192.  Its consumers read items 1-3 (anchors, offsets, fake feature maps),
-        which are constants of the input shape; the prediction-dependent items are not provided by
-        this path (None)."""
+        yolo3.py:1189-1192 — (box_preds (B,N,4), [anchors (1,1,3,2)]*3, [offsets (1,HW,1,2)]*3,
+        [fake feature maps (1,1,H,W)]*3, centers (B,N,2), scales (B,N,2), objness (B,N,1),
+        class_pred (B,N,C)), scales in the order stride 32, 16, 8.  Items 0 and 4-7 are device tensors
+        from one train-mode forward (BatchNorm on batch statistics); items 1-3 are constants of the input
+        shape (numpy), which is all the reference's consumer reads."""
         torch = _torch()
-        x = x if hasattr(x, "shape") else np.asarray(x)
+        x = self._as_input(x)
         b, _, h, w = x.shape
         anchors, offsets, fms = [], [], []
         table = [[116, 90, 156, 198, 373, 326], [30, 61, 62, 45, 59, 119], [10, 13, 16, 30, 33, 23]]
@@ -533,7 +551,15 @@ class YOLOV3(object):
             gx, gy = np.meshgrid(np.arange(ww), np.arange(hh))
             offsets.append(np.stack([gx, gy], -1).astype(np.float32).reshape(1, hh * ww, 1, 2))
             fms.append(np.zeros((1, 1, hh, ww), np.float32))
-        return (None, anchors, offsets, fms, None, None, None, None)
+        with torch.cuda.device(self._device):
+            self._ensure_plan(b, h, w, train=True)
+            n = self._lib.vy_net_num_anchors(self._h)
+            c = len(self._classes)
+            outs = [torch.empty((b, n, k), dtype=torch.float32, device=self._device) for k in (4, 2, 2, 1, c)]
+            _lib.check(self._lib.vy_net_train_mode_forward(
+                self._h, ctypes.c_void_p(x.data_ptr()), *[ctypes.c_void_p(t.data_ptr()) for t in outs],
+                self._stream()))
+        return (outs[0], anchors, offsets, fms, outs[1], outs[2], outs[3], outs[4])
 
     def grad(self, name):
         """Gradient of parameter `name` in the reference layout (numpy)."""
@@ -558,9 +584,13 @@ class YOLOV3(object):
         return out
 
     def _sync_opts(self):
+        """Parameter.lr_mult / wd_mult / grad_req -> the library's SGD segment table; only the rows that
+        changed since the last call are sent (steady state: no calls, no table re-upload)."""
         for p in self._params.values():
-            _lib.check(self._lib.vy_net_param_set_opt(self._h, p.index, float(p.lr_mult), float(p.wd_mult),
-                                                      int(p.trainable and p.grad_req != 'null')))
+            opt = (float(p.lr_mult), float(p.wd_mult), int(p.trainable and p.grad_req != 'null'))
+            if self._opts_sent.get(p.index) != opt:
+                _lib.check(self._lib.vy_net_param_set_opt(self._h, p.index, *opt))
+                self._opts_sent[p.index] = opt
 
     def sgd_step(self, lr, momentum, wd, rescale_grad):
         torch = _torch()

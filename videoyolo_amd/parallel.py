@@ -72,6 +72,29 @@ def allreduce_(tensor):
     return tensor
 
 
+def broadcast_(tensor, src=0):
+    """In-place broadcast from rank `src` (no-op without a process group)."""
+    if is_initialized() and world_size() > 1:
+        _dist().broadcast(tensor, src=src)
+    return tensor
+
+
+def sync_replicas(net, src=0):
+    """Make every rank's replica identical to rank `src`'s: one broadcast of the flat device parameter
+    buffer (weights, gamma/beta, running statistics) — what ``Trainer(kvstore='local')`` gives the
+    reference for free, because there ONE initialised copy is pushed to all devices
+    (train_yolov3.py:428,494,527-530).  With one process per GPU each rank runs its own
+    ``net.initialize()``, and an unseeded one draws different weights on every rank.  Called by
+    ``Trainer.__init__`` and (lazily, whenever parameters were written since the last sync) by the
+    recorded forward; collective — every rank must reach it."""
+    import torch
+    if not is_initialized() or world_size() == 1 or net._dev_params is None:
+        return False
+    broadcast_(net._dev_params.view(torch.float32), src)
+    net._replicas_synced = True
+    return True
+
+
 def gather_detections(ids, scores, bboxes):
     """Host gather of per-rank (B_r,100,·) results to rank 0 (detect_yolo3.py:233 as_numpy concat)."""
     import torch
@@ -98,6 +121,7 @@ class SyncBatchNormHook(object):
         import torch
         from . import _lib
         self.net = net
+        self.calls = []   # doubles per statistics exchange, in call order (6 layers forward + 6 backward per step)
 
         def cb(user, ptr, count):
             try:
@@ -105,6 +129,7 @@ class SyncBatchNormHook(object):
                 off = int(ptr) - ws.data_ptr()
                 view = ws[off:off + 8 * count].view(torch.float64)
                 _dist().all_reduce(view)
+                self.calls.append(int(count))
                 return 0
             except Exception:  # pragma: no cover - surfaced as a library error
                 import traceback
@@ -126,11 +151,13 @@ class GradBucketOverlap(object):
         self.net = net
         self.stream = torch.cuda.Stream(device=net._device) if net._device is not None else None
         self.pending = []
+        self.launched = []   # (element offset, element count) of every bucket handed to the all-reduce
 
         def cb(user, off, count):
             try:
                 if not is_initialized() or world_size() == 1:
                     return 0
+                self.launched.append((int(off), int(count)))
                 ev = torch.cuda.Event()
                 ev.record(torch.cuda.current_stream(net._device))
                 with torch.cuda.stream(self.stream):
@@ -145,6 +172,12 @@ class GradBucketOverlap(object):
         self._cb = _lib.GRAD_BUCKET_CB(cb)
         net._cb_keep.append(self._cb)
         _lib.check(net._lib.vy_net_set_grad_bucket_cb(net._h, self._cb, None))
+
+    def remove(self):
+        """Back to one all-reduce after backward: unregister the bucket callback."""
+        from . import _lib
+        self.finish()
+        _lib.check(self.net._lib.vy_net_set_grad_bucket_cb(self.net._h, _lib.GRAD_BUCKET_CB(), None))
 
     def finish(self):
         import torch

@@ -26,6 +26,9 @@ class Trainer(object):
         self._num_update = 0
         self._kvstore = kvstore
         self._overlap = None
+        # kvstore init: every device starts from the same parameters (rank 0's); if the parameters are not
+        # on the device yet the recorded forward does it (model.forward_train)
+        parallel.sync_replicas(self._net)
 
     @property
     def learning_rate(self):
@@ -40,20 +43,37 @@ class Trainer(object):
 
     def enable_overlap(self):
         """Overlap the gradient all-reduce with the backward pass (bucketed, side stream)."""
-        self._overlap = parallel.GradBucketOverlap(self._net)
+        if self._overlap is None:
+            self._overlap = parallel.GradBucketOverlap(self._net)
+
+    def disable_overlap(self):
+        if self._overlap is not None:
+            self._overlap.remove()
+            self._overlap = None
 
     def allreduce_grads(self):
+        """gluon.Trainer.allreduce_grads: sum the gradients over all ranks (after backward, before update)."""
+        if self._net._grads is None:
+            raise RuntimeError("allreduce_grads() before any recorded forward/backward")
         if self._overlap is not None:
             self._overlap.finish()
         else:
             parallel.allreduce_(self._net._grads)
 
-    def step(self, batch_size, ignore_stale_grad=False):
+    def update(self, batch_size, ignore_stale_grad=False):
+        """gluon.Trainer.update: the optimizer step on already all-reduced gradients."""
         net = self._net
         if net._grads is None:
-            raise RuntimeError("step() before any recorded forward/backward")
+            raise RuntimeError("update() before any recorded forward/backward")
+        if float(batch_size) <= 0:
+            raise ValueError("batch_size must be positive")
         self._num_update += 1
         lr = self.learning_rate
-        net._sync_opts()
-        self.allreduce_grads()
+        net._sync_opts()  # no-op unless a Parameter's lr_mult / wd_mult / grad_req changed
         net.sgd_step(lr, self._momentum, self._wd, 1.0 / float(batch_size))
+
+    def step(self, batch_size, ignore_stale_grad=False):
+        """trainer.step(batch_size) (train_yolov3.py:634) = allreduce_grads() + update(batch_size);
+        batch_size is the GLOBAL batch (rescale_grad = 1/batch_size)."""
+        self.allreduce_grads()
+        self.update(batch_size, ignore_stale_grad)
