@@ -136,7 +136,7 @@ def test_mxnet_params_container_roundtrip(voc_classes, tmp_path):
     f = str(tmp_path / "net.params")
     net.save_parameters(f, format="mxnet")
     raw = open(f, "rb").read()
-    assert struct.unpack_from("<QQQ", raw, 0) == (0x112, 0, 366)
+    assert struct.unpack_from("<QQQ", raw, 0) == (0x112, 0, 366 + 6)          # 366 tensors + 3 x (anchors, offsets)
     assert struct.unpack_from("<IiI", raw, 24) == (0xF993FAC9, 0, 4)          # first tensor: V2, dense, 4-D
     assert struct.unpack_from("<4q", raw, 36) == (32, 3, 3, 3)                  # stages.0.0.0.weight OIHW
     twin = _net(voc_classes[:3])
@@ -146,6 +146,41 @@ def test_mxnet_params_container_roundtrip(voc_classes, tmp_path):
     from videoyolo_amd import mxparams
     d = mxparams.load(f)
     assert list(d)[0] == "stages.0.0.0.weight" and d["yolo_outputs.2.prediction.bias"].shape == (24,)
+
+
+def test_checkpoints_carry_the_anchor_and_offset_constants(voc_classes, tmp_path):
+    """YOLOOutputV3 registers `anchors` and `offsets` as gluon Constants (yolo3.py:64-74); Constants are
+    Parameters, so the reference's save_parameters writes `yolo_outputs.{0,1,2}.anchors/.offsets` and its
+    load_parameters (train_yolov3.py:323-327, detect_yolo3.py:890: default ignore_extra=False,
+    allow_missing=False) expects them.  Both directions must work with exactly that call."""
+    from videoyolo_amd import mxparams
+    net = _net(voc_classes[:2])
+    net.initialize(init="synthetic", seed=3)
+    for fmt, name in ((None, "a.params"), ("mxnet", "b.params")):
+        f = str(tmp_path / name)
+        net.save_parameters(f, format=fmt)
+        d = mxparams.load(f) if fmt else dict(np.load(f))
+        keys = list(d)
+        assert d["yolo_outputs.0.anchors"].shape == (1, 1, 3, 2) and d["yolo_outputs.2.offsets"].shape == (1, 1, 128, 128, 2)
+        assert d["yolo_outputs.0.anchors"].reshape(-1).tolist() == [116, 90, 156, 198, 373, 326]     # anchors[::-1][0]
+        assert d["yolo_outputs.2.anchors"].reshape(-1).tolist() == [10, 13, 16, 30, 33, 23]
+        assert d["yolo_outputs.1.offsets"][0, 0, 5, 7].tolist() == [7, 5]                             # (x, y)
+        assert keys.index("yolo_outputs.1.anchors") < keys.index("yolo_outputs.1.prediction.weight")
+        twin = _net(voc_classes[:2])
+        twin.load_parameters(f)                                   # the reference's call: no ignore_extra
+        for k, p in net.collect_params().items():
+            assert np.array_equal(p.data(), twin.collect_params()[k].data())
+    # a file made with other anchors is refused, not silently run with the built-in ones
+    d = dict(np.load(str(tmp_path / "a.params")))
+    d["yolo_outputs.1.anchors"] = d["yolo_outputs.1.anchors"] * 2
+    with pytest.raises(ValueError):
+        _net(voc_classes[:2]).set_parameters(d)
+    # files without the constants (this package's round-1 .npz) still load
+    d = {k: v for k, v in d.items() if not k.endswith(("anchors", "offsets"))}
+    _net(voc_classes[:2]).set_parameters(d)
+    # int64 offsets (newer mxnet keeps the numpy dtype of the meshgrid) are accepted too
+    d["yolo_outputs.0.offsets"] = net.constants()["yolo_outputs.0.offsets"].astype(np.int64)
+    _net(voc_classes[:2]).set_parameters(d)
 
 
 def test_lr_schedule_of_the_training_script():

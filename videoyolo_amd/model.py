@@ -260,11 +260,37 @@ class YOLOV3(object):
         for i, p in enumerate(self._params.values()):
             self._set_param(i, vals[p.name])
 
+    _CONST_RE = re.compile(r"^yolo_outputs\.([0-2])\.(anchors|offsets)$")
+    _ANCHORS = ((116, 90, 156, 198, 373, 326), (30, 61, 62, 45, 59, 119), (10, 13, 16, 30, 33, 23))
+
+    def constants(self):
+        """The gluon Constants of the three YOLOOutputV3 blocks (yolo3.py:64-74).  Constants are Parameters,
+        so ``net.save_parameters`` of the reference writes them and its ``load_parameters`` expects them:
+        ``yolo_outputs.i.anchors`` (1,1,3,2) — ``anchors[::-1][i]`` of wrappers.py:80-84 — and
+        ``yolo_outputs.i.offsets`` (1,1,alloc_h,alloc_w,2), the (x, y) meshgrid.  Here they are compiled into
+        the library (net_internal.h kAnchors, the decode kernels' cell coordinates); this is their file image."""
+        out = OrderedDict()
+        ah, aw = self._alloc_size
+        gx, gy = np.meshgrid(np.arange(aw), np.arange(ah))
+        offsets = np.stack([gx, gy], -1).astype(np.float32)[None, None]
+        for i in range(3):
+            out["yolo_outputs.%d.anchors" % i] = np.array(self._ANCHORS[i], np.float32).reshape(1, 1, 3, 2)
+            out["yolo_outputs.%d.offsets" % i] = offsets.copy()
+        return out
+
     def save_parameters(self, filename, format=None):
-        """Gluon structural names, reference layouts.  Container: numpy .npz by default; mxnet's
+        """Gluon structural names, reference layouts, including the anchors / offsets Constants — the key set
+        of the reference's own ``net.save_parameters`` file.  Container: numpy .npz by default; mxnet's
         NDArray-dict layout with ``format='mxnet'`` (videoyolo_amd.mxparams: restated from memory,
         unverified against a real mxnet build — see INTEGRATION.md)."""
-        arrays = {p.name: self._get_param(p.index) for p in self._params.values()}
+        arrays = OrderedDict()
+        consts = self.constants()
+        for p in self._params.values():
+            m = re.match(r"^(yolo_outputs\.[0-2])\.prediction\.weight$", p.name)
+            if m:  # gluon order: a block's own parameters (anchors, offsets) before its children's
+                arrays[m.group(1) + ".anchors"] = consts[m.group(1) + ".anchors"]
+                arrays[m.group(1) + ".offsets"] = consts[m.group(1) + ".offsets"]
+            arrays[p.name] = self._get_param(p.index)
         if format == "mxnet":
             from . import mxparams
             mxparams.save(filename, arrays)
@@ -287,9 +313,28 @@ class YOLOV3(object):
             self.reset_ctx(ctx)
 
     def set_parameters(self, arrays, allow_missing=False, ignore_extra=False):
-        """Load a {structural name: array} dict (reference layouts)."""
+        """Load a {structural name: array} dict (reference layouts).  The anchors / offsets Constants of a
+        reference checkpoint are checked against the built-in ones (a file made with other anchors cannot be
+        run by this fixed-anchor path) and otherwise consumed silently; they may also be absent."""
+        consts = None
+        for k, v in arrays.items():
+            m = self._CONST_RE.match(k)
+            if not m:
+                continue
+            consts = consts or self.constants()
+            v = np.asarray(v, np.float32)
+            if m.group(2) == "anchors":
+                if v.size != 6 or not np.array_equal(v.reshape(-1), consts[k].reshape(-1)):
+                    raise ValueError("%s = %s differs from the yolo3_darknet53 anchors %s" %
+                                     (k, v.reshape(-1).tolist(), consts[k].reshape(-1).tolist()))
+            else:
+                g = v.reshape(v.shape[-3:]) if v.ndim >= 3 else v
+                want = consts[k][0, 0]
+                hh, ww = min(g.shape[0], want.shape[0]), min(g.shape[1], want.shape[1])
+                if g.ndim != 3 or g.shape[-1] != 2 or not np.array_equal(g[:hh, :ww], want[:hh, :ww]):
+                    raise ValueError("%s is not the (x, y) cell-offset meshgrid of yolo3.py:67-74" % k)
         missing = [k for k in self._params if k not in arrays]
-        extra = [k for k in arrays if k not in self._params]
+        extra = [k for k in arrays if k not in self._params and not self._CONST_RE.match(k)]
         if missing and not allow_missing:
             raise AssertionError("Parameter '%s' is missing in the file" % missing[0])
         if extra and not ignore_extra:
@@ -347,38 +392,26 @@ class YOLOV3(object):
         prediction convs, optionally re-using rows of the old predictors."""
         old_classes = self._classes
         classes = list(classes)
-        if isinstance(reuse_weights, (dict, list)):
-            if isinstance(reuse_weights, dict):
-                new_keys, new_vals = [], []
-                for k, v in reuse_weights.items():
-                    if isinstance(v, str):
-                        try:
-                            new_vals.append(old_classes.index(v))
-                        except ValueError:
-                            raise ValueError("{} not found in old class names {}".format(v, old_classes))
-                    else:
-                        if v < 0 or v >= len(old_classes):
-                            raise ValueError("Index {} out of bounds for old class names".format(v))
-                        new_vals.append(v)
-                    if isinstance(k, str):
-                        try:
-                            new_keys.append(classes.index(k))
-                        except ValueError:
-                            raise ValueError("{} not found in new class names {}".format(k, classes))
-                    else:
-                        if k < 0 or k >= len(classes):
-                            raise ValueError("Index {} out of bounds for new class names".format(k))
-                        new_keys.append(k)
-                reuse_weights = dict(zip(new_keys, new_vals))
-            else:
-                new_map = {}
-                for x in reuse_weights:
-                    try:
-                        new_map[classes.index(x)] = old_classes.index(x)
-                    except ValueError:
-                        warnings.warn("{} not found in old: {} or new class names: {}".format(
-                            x, old_classes, classes))
-                reuse_weights = new_map
+
+        def resolve(ref, names, which):
+            """A class given by name or by index -> index into `names`; same errors as yolo3.py:1270-1286."""
+            if isinstance(ref, str):
+                if ref not in names:
+                    raise ValueError("{} not found in {} class names {}".format(ref, which, names))
+                return names.index(ref)
+            if ref < 0 or ref >= len(names):
+                raise ValueError("Index {} out of bounds for {} class names".format(ref, which))
+            return ref
+
+        if isinstance(reuse_weights, dict):      # {new class: old class}, names or indices on either side
+            reuse_weights = {resolve(new, classes, "new"): resolve(old, old_classes, "old")
+                             for new, old in reuse_weights.items()}
+        elif isinstance(reuse_weights, list):    # names present in both lists keep their weights
+            both = [n for n in reuse_weights if n in classes and n in old_classes]
+            for n in reuse_weights:
+                if n not in both:
+                    warnings.warn("{} not found in old: {} or new class names: {}".format(n, old_classes, classes))
+            reuse_weights = {classes.index(n): old_classes.index(n) for n in both}
         old_vals = {p.name: self._get_param(p.index) for p in self._params.values()}
         device = self._device
         fresh = YOLOV3(classes, self.nms_thresh, self.nms_topk, self.post_nms, self._pos_iou_thresh,
