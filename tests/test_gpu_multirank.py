@@ -70,14 +70,15 @@ def test_parameters_are_broadcast_from_rank0(ranks, problem):
         assert np.array_equal(r["bcast_after"], params[name])
 
 
-def test_bucketed_overlap_equals_plain_allreduce(ranks):
+def test_bucketed_overlap_equals_plain_allreduce(ranks, problem):
+    trainable = sum(v.size for k, v in problem[0].items() if "running" not in k)
     for r in ranks:
         assert bool(r["A_overlap_equals_plain"])
         assert float(r["A_grad_absmax"]) > 0
         b = r["A_buckets"]
         assert b.shape == (4, 2)                                          # heads, stages.2, stages.1, stages.0
         assert (np.diff(b[:, 0]) < 0).all()                               # deep -> shallow: descending offsets
-        assert b[:, 1].sum() >= 61626049                                  # the buckets cover every trainable tensor
+        assert b[:, 1].sum() >= trainable                                 # the buckets cover every trainable tensor
 
 
 def _check_against_oracle(ranks, problem, phase, sync_bn):

@@ -27,6 +27,8 @@ def is_training():
 def _scope(recording, training):
     s = _get()
     prev = (s.recording, s.training)
+    if recording and not s.recording:
+        s.tape = []  # a fresh recording: forwards recorded earlier and never back-propagated are dropped
     if recording is not None:
         s.recording = recording
     if training is not None:
@@ -124,11 +126,12 @@ def backward(heads, head_grads=None, retain_graph=False, train_mode=True):
                 "autograd.backward: a head is not a sum of a net's loss vectors (built with anything but '+'); "
                 "only backward(obj_loss + center_loss + scale_loss + cls_loss) is supported")
         got.update(terms)
-    want = collections.Counter({(id(net), i): 1 for net in tape for i in range(4)})
-    if got != want:
+    nets = [net for net in tape if any(nid == id(net) for nid, _ in got)]
+    want = collections.Counter({(id(net), i): 1 for net in nets for i in range(4)})
+    if not nets or got != want:
         raise NotImplementedError(
-            "autograd.backward: heads must be exactly obj_loss + center_loss + scale_loss + cls_loss of every "
-            "recorded net (train_yolov3.py:626); got loss indices %s" % sorted(i for (_, i), _ in got.items()))
-    s.tape = []
-    for net in tape:
+            "autograd.backward: heads must be exactly obj_loss + center_loss + scale_loss + cls_loss of a recorded "
+            "net (train_yolov3.py:626); got loss indices %s" % sorted(i for (_, i), _ in got.items()))
+    s.tape = [net for net in tape if net not in nets]
+    for net in nets:
         net.backward()

@@ -31,6 +31,7 @@
 // 128x128 tile: 66 KiB of LDS -> 2 blocks / CU, 64 accumulator VGPRs / lane.
 // dgrad reads W as the [k][n] operand: its LDS tile is 32 k-rows of BN contiguous floats, read with
 // ds_read_b32 (32 consecutive floats per half-wave: conflict-free without a swizzle).
+#include <cstdio>
 #include <cstdlib>
 #include <type_traits>
 
@@ -421,6 +422,9 @@ static hipError_t launch_cfg(const ConvArgs& a, hipStream_t s) {
 // at batch 16) and the narrow-N dgrads fall back to 128x64 and then 64x64 tiles.
 static void select_cfg(const ConvArgs& a, int* bm, int* bn) {
   auto blocks = [&](int m, int n) { return (long long)((a.M + m - 1) / m) * ((a.N + n - 1) / n); };
+  // experiment switch (tools/tile_sweep.sh): VY_CONV_FORCE=128x64 runs every launch on that tile
+  static const char* force = getenv("VY_CONV_FORCE");
+  if (force && sscanf(force, "%dx%d", bm, bn) == 2) return;
   if (a.N <= 32) {
     *bm = 128;
     *bn = 32;

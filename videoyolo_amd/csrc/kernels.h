@@ -119,8 +119,11 @@ struct BnFinalizeArgs {
   float eps, momentum;
 };
 hipError_t vy_launch_bn_finalize(const BnFinalizeArgs& a, hipStream_t s);
-// ordered reduce of the [n_part][2][C] partial sums + finalize in one launch (per-device BatchNorm)
-hipError_t vy_launch_bn_reduce_finalize(const double* partials, int n_part, const BnFinalizeArgs& a, hipStream_t s);
+// ordered reduce of the [n_part][2][C] partial sums + finalize (per-device BatchNorm): one launch, or — more than
+// 2 * VY_REDUCE_SLICES rows and a scratch of VY_REDUCE_SLICES * 2 * C doubles given — a slice-sum launch first
+#define VY_REDUCE_SLICES 64
+hipError_t vy_launch_bn_reduce_finalize(const double* partials, int n_part, const BnFinalizeArgs& a, double* scratch,
+                                        hipStream_t s);
 
 // a = leaky(fma(z, scale, shift)) (+ res), z plane (B,H+2,W+2,C) -> output view (x1 or x2 replicate)
 struct BnApplyArgs {
@@ -148,8 +151,9 @@ struct BnBwdArgs {
   float* partials;        // [n_chunks][2][C]  (reduce pass)
   int B, H, W, C;
   int g_Hp, g_Wp, g_cs, g_co, ups;
-  int chunk;              // pixels per partial chunk
+  int chunk;              // image rows (b, y) per partial chunk: vy_bn_bwd_rows_per_chunk
 };
+int vy_bn_bwd_rows_per_chunk(int B, int H, int C);
 int vy_bn_bwd_chunks(const BnBwdArgs& a);
 hipError_t vy_launch_bn_bwd_reduce(const BnBwdArgs& a, hipStream_t s);
 struct BnBwdFinalizeArgs {

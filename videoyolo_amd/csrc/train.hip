@@ -37,7 +37,7 @@ struct VyTrain {
   float ignore_iou = 0.7f;
   int label_smooth = 0;
   // regions (byte offsets in the workspace)
-  size_t g_off = 0, z_off = 0, save_off = 0, coef_off = 0, sums_off = 0, part_off = 0, slab_off = 0;
+  size_t g_off = 0, z_off = 0, save_off = 0, coef_off = 0, sums_off = 0, slice_off = 0, part_off = 0, slab_off = 0;
   size_t loss_part_off = 0, loss_off = 0, zero_off = 0, seg_off = 0, chunk_off = 0, total = 0;
   size_t part_floats = 0, slab_floats = 0;
   std::vector<ZPlane> z;               // per conv
@@ -75,14 +75,7 @@ namespace {
 
 size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 
-constexpr int kBwdChunk = 64;  // pixels per partial-sum block of the BN-backward / bias-gradient reductions
-
-// BN-backward partial sums: 64 pixels per block on the small maps (enough blocks to fill the chip), more
-// on the large ones so that the ordered second stage stays at <= ~1024 rows
-inline int bwd_chunk(long long npix) {
-  if (npix <= 64 * 1024) return kBwdChunk;
-  return (int)(((npix / 1024) + 63) / 64 * 64);
-}
+constexpr int kBwdChunk = 64;  // pixels per partial-sum block of the bias-gradient reductions (and the scratch bound)
 
 bool is_sync_layer(const ConvT& c) {
   // the layers Darknet3D builds with the passed norm_layer: the stem and the stride-2 convs
@@ -169,6 +162,8 @@ size_t train_plan(vy_net* net, int b, int h, int w, bool commit) {
   off += al256(3 * 1024 * sizeof(float));
   const size_t sums_off = off;
   off += al256(2 * 2 * 1024 * sizeof(double));  // [global | local] x [2][C]
+  const size_t slice_off = off;
+  off += al256((size_t)VY_REDUCE_SLICES * 2 * 1024 * sizeof(double));  // slice sums of long per-tile statistics lists
   const size_t part_off = off;
   off += al256(part * sizeof(float));
   const size_t slab_off = off;
@@ -218,6 +213,7 @@ size_t train_plan(vy_net* net, int b, int h, int w, bool commit) {
     t->save_off = save_off;
     t->coef_off = coef_off;
     t->sums_off = sums_off;
+    t->slice_off = slice_off;
     t->part_off = part_off;
     t->slab_off = slab_off;
     t->loss_part_off = loss_part_off;
@@ -249,6 +245,7 @@ struct TrainCtx {
   float* coef() const { return reinterpret_cast<float*>(net->dev_ws + t->coef_off); }
   double* sums_global() const { return reinterpret_cast<double*>(net->dev_ws + t->sums_off); }
   double* sums_local() const { return sums_global() + 2 * 1024; }
+  double* slice_sums() const { return reinterpret_cast<double*>(net->dev_ws + t->slice_off); }
   float* partials() const { return reinterpret_cast<float*>(net->dev_ws + t->part_off); }
   float* slabs() const { return reinterpret_cast<float*>(net->dev_ws + t->slab_off); }
   const float* zero() const { return reinterpret_cast<const float*>(net->dev_ws + t->zero_off); }
@@ -338,7 +335,7 @@ int forward_train(const TrainCtx& c, const float* x) {
     if (exchange)
       HIP_TRY(vy_launch_bn_finalize(f, c.s));
     else
-      HIP_TRY(vy_launch_bn_reduce_finalize(reinterpret_cast<const double*>(c.partials()), n_part, f, c.s));
+      HIP_TRY(vy_launch_bn_reduce_finalize(reinterpret_cast<const double*>(c.partials()), n_part, f, c.slice_sums(), c.s));
     BnApplyArgs ap;
     memset(&ap, 0, sizeof ap);
     ap.z = c.zplane((int)ci);
@@ -564,7 +561,7 @@ int backward_train(const TrainCtx& c, const float* x) {
       bb.g_cs = op.C;
       bb.g_co = cv.out_co;
       bb.ups = cv.ups;
-      bb.chunk = bwd_chunk((long long)B * zp.H * zp.W);
+      bb.chunk = vy_bn_bwd_rows_per_chunk(B, zp.H, cv.cout);
       HIP_TRY(vy_launch_bn_bwd_reduce(bb, c.s));
       const bool exchange = c.t->world > 1 && is_sync_layer(cv);
       double count = (double)B * zp.H * zp.W;

@@ -82,26 +82,48 @@ __global__ void bn_finalize_kernel(const BnFinalizeArgs a) {
 }
 
 // Per-device BatchNorm (no statistics exchange between the reduce and the finalize): both in one launch.
-// Block = 32 channels x 32 row groups, the same summation tree as reduce_partials_kernel, for the
-// channel's two columns (sum, sum of squares) at once.
+// Block = kRfCols channels x kRfGroups row groups; row group r sums partial rows r, r + kRfGroups, ... in that
+// order (eight loads in flight at a time: the loop is latency-bound, not bandwidth-bound), then the group sums
+// are added in group order: a fixed summation tree, for the channel's two columns (sum, sum of squares) at once.
+constexpr int kRfCols = 16, kRfGroups = 64;
+
 template <typename T, typename Args, typename Fin>
 __device__ __forceinline__ void reduce2_finalize(const T* __restrict__ partials, int n_part, const Args& a, Fin fin) {
-  __shared__ double red[2][32][33];
-  const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
-  const int c = blockIdx.x * 32 + cx;
+  __shared__ double red[2][kRfGroups][kRfCols + 1];
+  const int cx = threadIdx.x % kRfCols, ry = threadIdx.x / kRfCols;
+  const int c = blockIdx.x * kRfCols + cx;
   double acc1 = 0.0, acc2 = 0.0;
-  if (c < a.C)
-    for (int t = ry; t < n_part; t += 32) {
-      acc1 += (double)partials[(long long)t * 2 * a.C + c];
-      acc2 += (double)partials[(long long)t * 2 * a.C + a.C + c];
+  if (c < a.C) {
+    const T* p1 = partials + c;
+    const T* p2 = partials + a.C + c;
+    const long long rs = 2LL * a.C;
+    int t = ry;
+    constexpr int U = 8;
+    for (; t + (U - 1) * kRfGroups < n_part; t += U * kRfGroups) {
+      T v1[U], v2[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        v1[u] = p1[(long long)(t + u * kRfGroups) * rs];
+        v2[u] = p2[(long long)(t + u * kRfGroups) * rs];
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        acc1 += (double)v1[u];
+        acc2 += (double)v2[u];
+      }
     }
+    for (; t < n_part; t += kRfGroups) {
+      acc1 += (double)p1[(long long)t * rs];
+      acc2 += (double)p2[(long long)t * rs];
+    }
+  }
   red[0][ry][cx] = acc1;
   red[1][ry][cx] = acc2;
   __syncthreads();
   if (ry == 0 && c < a.C) {
     double s1 = 0.0, s2 = 0.0;
-#pragma unroll
-    for (int r = 0; r < 32; ++r) {
+#pragma unroll 8
+    for (int r = 0; r < kRfGroups; ++r) {
       s1 += red[0][r][cx];
       s2 += red[1][r][cx];
     }
@@ -115,8 +137,53 @@ __global__ __launch_bounds__(1024) void bn_reduce_finalize_kernel(const double* 
                    [](const BnFinalizeArgs& f, int c, double s1, double s2) { bn_finalize_channel(f, c, s1, s2); });
 }
 
-hipError_t vy_launch_bn_reduce_finalize(const double* partials, int n_part, const BnFinalizeArgs& a, hipStream_t s) {
-  hipLaunchKernelGGL(bn_reduce_finalize_kernel, dim3((a.C + 31) / 32), dim3(1024), 0, s, partials, n_part, a);
+// first stage for long partial lists (the 208x208 / 104x104 layers produce thousands of per-tile rows): S row
+// slices are summed by S x (n_cols / kRfCols) blocks into out[S][n_cols] (double), which the launch above then
+// finishes — two short launches instead of one launch whose C / 16 blocks walk every row.  Order: rows of a
+// slice by row group as above, groups in order: fixed.
+__global__ __launch_bounds__(1024) void reduce_slices_kernel(const double* __restrict__ partials, int n_part, int n_cols,
+                                                             int rows_per_slice, double* __restrict__ out) {
+  __shared__ double red[kRfGroups][kRfCols + 1];
+  const int cx = threadIdx.x % kRfCols, ry = threadIdx.x / kRfCols;
+  const int c = blockIdx.x * kRfCols + cx;
+  const int t0 = blockIdx.y * rows_per_slice;
+  const int t1 = t0 + rows_per_slice < n_part ? t0 + rows_per_slice : n_part;
+  double acc = 0.0;
+  if (c < n_cols) {
+    int t = t0 + ry;
+    constexpr int U = 8;
+    for (; t + (U - 1) * kRfGroups < t1; t += U * kRfGroups) {
+      double v[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) v[u] = partials[(long long)(t + u * kRfGroups) * n_cols + c];
+#pragma unroll
+      for (int u = 0; u < U; ++u) acc += v[u];
+    }
+    for (; t < t1; t += kRfGroups) acc += partials[(long long)t * n_cols + c];
+  }
+  red[ry][cx] = acc;
+  __syncthreads();
+  if (ry == 0 && c < n_cols) {
+    double s = 0.0;
+#pragma unroll 8
+    for (int r = 0; r < kRfGroups; ++r) s += red[r][cx];
+    out[(long long)blockIdx.y * n_cols + c] = s;
+  }
+}
+
+hipError_t vy_launch_bn_reduce_finalize(const double* partials, int n_part, const BnFinalizeArgs& a, double* scratch,
+                                        hipStream_t s) {
+  if (n_part > 2 * VY_REDUCE_SLICES && scratch) {
+    const int S = VY_REDUCE_SLICES;
+    const int rps = (n_part + S - 1) / S;
+    const int slices = (n_part + rps - 1) / rps;
+    hipLaunchKernelGGL(reduce_slices_kernel, dim3((2 * a.C + kRfCols - 1) / kRfCols, slices), dim3(1024), 0, s, partials,
+                       n_part, 2 * a.C, rps, scratch);
+    partials = scratch;
+    n_part = slices;
+  }
+  hipLaunchKernelGGL(bn_reduce_finalize_kernel, dim3((a.C + kRfCols - 1) / kRfCols), dim3(1024), 0, s, partials, n_part,
+                     a);
   return hipGetLastError();
 }
 
@@ -180,32 +247,58 @@ __device__ __forceinline__ f32x4 load_da(const BnBwdArgs& a, int b, int y, int x
   return r;
 }
 
-int vy_bn_bwd_chunks(const BnBwdArgs& a) {
-  const long long npix = (long long)a.B * a.H * a.W;
-  return (int)((npix + a.chunk - 1) / a.chunk);
+// Sums of dy and dy*xhat over the pixels, per channel: the two planes (z, and the gradient of the cell's output)
+// are read exactly once, 16 B per lane.  Block = CQ channel quads x PY pixel lanes (512 threads); a block owns
+// `a.chunk` consecutive image rows (b, y), walks them with incrementally updated coordinates (no division in
+// the loop) two pixels at a time (two independent accumulator sets: twice the loads in flight), and writes one
+// partial row [2][C]; the ordered second stage (bn_bwd_reduce_finalize) adds the rows in index order.
+constexpr int kBwdThreads = 512;
+
+int vy_bn_bwd_rows_per_chunk(int B, int H, int C) {
+  const int cq = C >> 2;
+  const int CQ = cq < 64 ? cq : 64;
+  const int groups = (cq + CQ - 1) / CQ;
+  int want = 1024 / groups;  // ~4 blocks per CU over the whole launch, <= 1024 partial rows
+  if (want < 1) want = 1;
+  const int rows = B * H;
+  return (rows + want - 1) / want;
 }
 
-__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const BnBwdArgs a, int CQ) {
-  __shared__ float red[2][256][4];
-  const int PY = 256 / CQ;
+int vy_bn_bwd_chunks(const BnBwdArgs& a) { return (a.B * a.H + a.chunk - 1) / a.chunk; }
+
+__global__ __launch_bounds__(kBwdThreads) void bn_bwd_reduce_kernel(const BnBwdArgs a, int CQ) {
+  __shared__ float red[2][kBwdThreads][4];
+  const int PY = kBwdThreads / CQ;
   const int tq = threadIdx.x % CQ, py = threadIdx.x / CQ;
   const int c = (blockIdx.x * CQ + tq) << 2;
-  const long long npix = (long long)a.B * a.H * a.W;
-  const long long p0 = (long long)blockIdx.y * a.chunk;
-  long long p1 = p0 + a.chunk;
-  if (p1 > npix) p1 = npix;
-  f32x4 s1 = {0, 0, 0, 0}, s2 = {0, 0, 0, 0};
+  const int rows = a.B * a.H;
+  const int r0 = blockIdx.y * a.chunk;
+  const int r1 = r0 + a.chunk < rows ? r0 + a.chunk : rows;
+  f32x4 s1a = {0, 0, 0, 0}, s2a = {0, 0, 0, 0}, s1b = {0, 0, 0, 0}, s2b = {0, 0, 0, 0};
   if (c < a.C) {
     const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scale + c);
     const f32x4 sh = *reinterpret_cast<const f32x4*>(a.shift + c);
     const f32x4 mu = *reinterpret_cast<const f32x4*>(a.save_mean + c);
     const f32x4 is = *reinterpret_cast<const f32x4*>(a.save_invstd + c);
-    for (long long p = p0 + py; p < p1; p += PY) {
-      const int x = (int)(p % a.W);
-      const long long t = p / a.W;
-      const int y = (int)(t % a.H), b = (int)(t / a.H);
-      const f32x4 z = *reinterpret_cast<const f32x4*>(a.z + ((long long)(b * (a.H + 2) + y + 1) * (a.W + 2) + x + 1) * a.C + c);
-      const f32x4 da = load_da(a, b, y, x, c);
+    // pixel lane py starts at pixel py of the chunk and advances by PY pixels = (dq rows, dr columns)
+    const int dq = PY / a.W, dr = PY - dq * a.W;
+    int row = r0 + py / a.W, x = py % a.W;
+    int b = row / a.H, y = row - b * a.H;
+    auto advance = [&]() {
+      x += dr;
+      row += dq;
+      y += dq;
+      if (x >= a.W) {
+        x -= a.W;
+        ++row;
+        ++y;
+      }
+      while (y >= a.H) {
+        y -= a.H;
+        ++b;
+      }
+    };
+    auto accumulate = [&](const f32x4& z, const f32x4& da, f32x4& s1, f32x4& s2) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const float yv = fmaf(z[i], sc[i], sh[i]);
@@ -214,17 +307,53 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const BnBwdArgs a, i
         s1[i] += dy;
         s2[i] = fmaf(dy, xh, s2[i]);
       }
+    };
+    auto zptr = [&]() {
+      return a.z + ((long long)(b * (a.H + 2) + y + 1) * (a.W + 2) + x + 1) * a.C + c;
+    };
+    while (row < r1) {
+      const f32x4 z0 = *reinterpret_cast<const f32x4*>(zptr());
+      const f32x4 d0 = load_da(a, b, y, x, c);
+      advance();
+      if (row < r1) {
+        const f32x4 z1 = *reinterpret_cast<const f32x4*>(zptr());
+        const f32x4 d1 = load_da(a, b, y, x, c);
+        advance();
+        accumulate(z0, d0, s1a, s2a);
+        accumulate(z1, d1, s1b, s2b);
+      } else {
+        accumulate(z0, d0, s1a, s2a);
+      }
     }
   }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    red[0][threadIdx.x][i] = s1[i];
-    red[1][threadIdx.x][i] = s2[i];
+    red[0][threadIdx.x][i] = s1a[i] + s1b[i];
+    red[1][threadIdx.x][i] = s2a[i] + s2b[i];
+  }
+  __syncthreads();
+  // fixed tree: pixel lanes py, py+8, py+16, ... first (8 or fewer partial sums per channel quad), then those in order
+  const int P8 = PY < 8 ? PY : 8;
+  f32x4 u1 = {0, 0, 0, 0}, u2 = {0, 0, 0, 0};
+  if (py < P8)
+    for (int r = py; r < PY; r += P8)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        u1[i] += red[0][r * CQ + tq][i];
+        u2[i] += red[1][r * CQ + tq][i];
+      }
+  __syncthreads();
+  if (py < P8) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      red[0][threadIdx.x][i] = u1[i];
+      red[1][threadIdx.x][i] = u2[i];
+    }
   }
   __syncthreads();
   if (py == 0 && c < a.C) {
     f32x4 t1 = {0, 0, 0, 0}, t2 = {0, 0, 0, 0};
-    for (int r = 0; r < PY; ++r)
+    for (int r = 0; r < P8; ++r)
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         t1[i] += red[0][r * CQ + tq][i];
@@ -237,11 +366,11 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const BnBwdArgs a, i
 }
 
 hipError_t vy_launch_bn_bwd_reduce(const BnBwdArgs& a, hipStream_t s) {
-  if ((a.C & 3) || (a.g_cs & 3) || (a.g_co & 3)) return hipErrorInvalidValue;
+  if ((a.C & 3) || (a.g_cs & 3) || (a.g_co & 3) || a.chunk < 1) return hipErrorInvalidValue;
   const int cq = a.C >> 2;
   const int CQ = cq < 64 ? cq : 64;
-  if (256 % CQ) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((cq + CQ - 1) / CQ, vy_bn_bwd_chunks(a)), dim3(256), 0, s, a, CQ);
+  if (kBwdThreads % CQ) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((cq + CQ - 1) / CQ, vy_bn_bwd_chunks(a)), dim3(kBwdThreads), 0, s, a, CQ);
   return hipGetLastError();
 }
 
@@ -270,7 +399,8 @@ __global__ __launch_bounds__(1024) void bn_bwd_reduce_finalize_kernel(const floa
 
 hipError_t vy_launch_bn_bwd_reduce_finalize(const float* partials, int n_part, const BnBwdFinalizeArgs& a,
                                             hipStream_t s) {
-  hipLaunchKernelGGL(bn_bwd_reduce_finalize_kernel, dim3((a.C + 31) / 32), dim3(1024), 0, s, partials, n_part, a);
+  hipLaunchKernelGGL(bn_bwd_reduce_finalize_kernel, dim3((a.C + kRfCols - 1) / kRfCols), dim3(1024), 0, s, partials,
+                     n_part, a);
   return hipGetLastError();
 }
 
