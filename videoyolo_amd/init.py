@@ -9,6 +9,8 @@
               (1 + 0.45*0.25)^n_blocks, so activations stay O(1) through all 75 layers and the heads
               produce a realistic spread of scores; BN statistics near identity.
 """
+import zlib
+
 import numpy as np
 
 RES_GAIN = 0.25
@@ -17,10 +19,18 @@ _AFTER_BLOCKS = {"stages.0.3": 1, "stages.0.6": 2, "stages.1.0": 8, "stages.2.0"
                  "yolo_blocks.0.body.0": 4}
 
 
+def _rng(seed, name):
+    """One generator per (seed, tensor name): a tensor's values do not depend on the order of the table
+    (the library's parameter table and the oracle's list the heads in different orders)."""
+    if seed is None:
+        return np.random.default_rng()
+    return np.random.default_rng([int(seed), zlib.crc32(name.encode())])
+
+
 def uniform_params(table, seed=None, scale=0.07):
-    rng = np.random.default_rng(seed)
     out = {}
     for name, shape in table:
+        rng = _rng(seed, name)
         leaf = name.rsplit(".", 1)[1]
         if leaf == "weight":
             out[name] = rng.uniform(-scale, scale, shape).astype(np.float32)
@@ -34,9 +44,9 @@ def uniform_params(table, seed=None, scale=0.07):
 def synthetic_params(table, seed=233, obj_bias=0.0):
     """table: [(structural name, reference shape)].  obj_bias is added to the objectness rows of the
     three prediction biases (obj_bias = -5 gives a 'trained-like' sparse candidate set)."""
-    rng = np.random.default_rng(seed)
     out = {}
     for name, shape in table:
+        rng = _rng(seed, name)
         leaf = name.rsplit(".", 1)[1]
         if leaf == "weight":
             fan = shape[1] * shape[2] * shape[3]
