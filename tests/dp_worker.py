@@ -81,6 +81,8 @@ def main():
     trainer.allreduce_grads()
     torch.cuda.synchronize()
     g_overlap = net._grads.clone()
+    for n in RUNNING:                                   # after ONE recorded forward
+        out["A_running/" + n] = net.collect_params()[n].data()
     out["A_buckets"] = np.array(trainer._overlap.launched, np.int64)
     trainer.disable_overlap()
     fwd_bwd(net)
@@ -90,8 +92,6 @@ def main():
     out["A_grad_absmax"] = np.array(float(g_overlap.abs().max()))
     for n in WATCH:
         out["A_grad/" + n] = net.grad(n)
-    for n in RUNNING:
-        out["A_running/" + n] = net.collect_params()[n].data()
     del net, trainer, g_overlap
 
     # ---- B. SyncBatchNorm + one full Trainer.step

@@ -75,6 +75,30 @@ namespace {
 
 size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 
+// Profiling aid (tools/train_layers.py): with VY_TRAIN_LABELS=<path> the first training step appends one line per
+// matrix-core launch — kind (fwd / wgrad / dgrad), cell name, FLOPs, GEMM dims — so that a rocprofv3 kernel trace
+// can be joined with the layers by launch order within each kernel class.
+struct LabelLog {
+  FILE* f = nullptr;
+  bool open_once() {
+    static const char* path = getenv("VY_TRAIN_LABELS");
+    if (!path) return false;
+    if (!f) f = fopen(path, "w");
+    return f != nullptr;
+  }
+  void note(const char* kind, const std::string& name, double M, double N, double K) {
+    if (open_once()) fprintf(f, "%s %s %.0f %.0f %.0f %.0f\n", kind, name.c_str(), 2.0 * M * N * K, M, N, K);
+  }
+  void close_step() {
+    if (f) {
+      fclose(f);
+      f = nullptr;
+    }
+  }
+};
+LabelLog g_labels;
+bool g_labels_done = false;
+
 constexpr int kBwdChunk = 64;  // pixels per partial-sum block of the bias-gradient reductions (and the scratch bound)
 
 bool is_sync_layer(const ConvT& c) {
@@ -273,6 +297,7 @@ int forward_train(const TrainCtx& c, const float* x) {
     const ConvT& cv = net->convs[ci];
     if (cv.p_gamma < 0) {  // prediction conv: bias, no BN
       const ConvArgs a = net->conv_args(cv);
+      if (!g_labels_done) g_labels.note("fwd", cv.name, a.M, a.N, (double)a.ntaps * a.Kc);
       HIP_TRY(vy_launch_conv_igemm(a, c.s));
       continue;
     }
@@ -304,6 +329,7 @@ int forward_train(const TrainCtx& c, const float* x) {
       a.o_s = 1;
       a.ups = 1;
       a.stats = reinterpret_cast<double*>(c.partials());
+      if (!g_labels_done) g_labels.note("fwd", cv.name, a.M, a.N, (double)a.ntaps * a.Kc);
       HIP_TRY(vy_launch_conv_igemm(a, c.s));
       n_part = vy_conv_tiles_m(a);
     }
@@ -460,6 +486,7 @@ int launch_wgrad(const TrainCtx& c, size_t ci, const float* dzp, int dz_cs, int 
   w.Cin = cv.cin;
   w.splits = c.t->splits[ci];
   w.k_per_split = c.t->kps[ci];
+  if (!g_labels_done) g_labels.note("wgrad", cv.name, w.M, w.Cout, (double)cv.k * cv.k * cv.cin);
   HIP_TRY(vy_launch_wgrad(w, ws));
   HIP_TRY(vy_launch_slab_reduce(c.slabs(), w.splits, (long long)cv.cout * cv.k * cv.k * cv.cin,
                                 c.grad_of(cv.p_weight), ws));
@@ -636,12 +663,19 @@ int backward_train(const TrainCtx& c, const float* x) {
       add_co = cv.in_co;
     }
     const BwdDgrad dg = make_dgrad(c, cv, dzp, dz_cs, dzH, dzW, addend, add_cs, add_co);
-    for (int k = 0; k < dg.n; ++k) HIP_TRY(vy_launch_conv_igemm(dg.a[k], c.s));
+    for (int k = 0; k < dg.n; ++k) {
+      if (!g_labels_done) g_labels.note("dgrad", cv.name, dg.a[k].M, dg.a[k].N, (double)dg.a[k].ntaps * dg.a[k].Kc);
+      HIP_TRY(vy_launch_conv_igemm(dg.a[k], c.s));
+    }
     if (cov == 0) touched[cv.in_plane].push_back({lo, hi});
   }
   if (int rc = emit_bucket(cur_bucket)) return rc;
   if (int rc = join_side()) return rc;
   if (!skips.empty()) return fail(VY_ERR_STATE, "internal: unresolved skip gradient");
+  if (!g_labels_done && g_labels.f) {
+    g_labels.close_step();
+    g_labels_done = true;
+  }
   return 0;
 }
 
