@@ -417,12 +417,18 @@ static hipError_t launch_cfg(const ConvArgs& a, hipStream_t s) {
   return hipGetLastError();
 }
 
-// Tile choice: the 128x128 tile has the best arithmetic intensity, but a launch needs >= ~2 blocks
-// per CU slot (256 CUs x 2 resident blocks) to fill the chip; small-M layers (13x13 and 26x26 maps
-// at batch 16) and the narrow-N dgrads fall back to 128x64 and then 64x64 tiles.
+// Tile choice.  Measured on the MI355X (tools/train_layers.sh with VY_CONV_FORCE, 416x416 batch 16 and 608x608
+// batch 64): a launch of T tiles takes ceil(T / 256) x (alpha(tile) x K + O(tile)) — every CU works through its
+// share of the tiles at a rate that does not depend on how many blocks it holds (2 resident 128x128 blocks, 3 of
+// 128x64, 4 of 64x64), and what is lost is the last, partly filled round of the 256 CUs.  Fitted per tile, in
+// microseconds: alpha = 0.0634 / 0.0347 / 0.0177 per unit of K (128x64 costs 0.547 of 128x128, not 0.5: twice the
+// LDS-DMA bytes per FLOP), fixed part O = 6.7 / 1.8 / 1.0 (prologue tables + the epilogue of 64 / 32 / 16
+// accumulator registers per lane): short-K 1x1 layers prefer the small tiles, long-K 3x3 layers the large one.
+// The smallest predicted time wins; a smaller tile has to be better by 0.5 %.  (A two-wave 64x32 tile was tried
+// for the 13x13 maps at batch 16, which are short of blocks: 461 vs 337 us on the K = 9216 data gradients.)
 static void select_cfg(const ConvArgs& a, int* bm, int* bn) {
   auto blocks = [&](int m, int n) { return (long long)((a.M + m - 1) / m) * ((a.N + n - 1) / n); };
-  // experiment switch (tools/tile_sweep.sh): VY_CONV_FORCE=128x64 runs every launch on that tile
+  // experiment switch (tools/train_layers.sh): VY_CONV_FORCE=128x64 runs every launch on that tile
   static const char* force = getenv("VY_CONV_FORCE");
   if (force && sscanf(force, "%dx%d", bm, bn) == 2) return;
   if (a.N <= 32) {
@@ -430,16 +436,22 @@ static void select_cfg(const ConvArgs& a, int* bm, int* bn) {
     *bn = 32;
     return;
   }
-  const long long want = 1024;
-  if (a.N > 64 && blocks(128, 128) >= want) {
-    *bm = 128;
-    *bn = 128;
-  } else if (blocks(128, 64) >= want || a.M <= 64) {
-    *bm = 128;
-    *bn = 64;
-  } else {
-    *bm = 64;
-    *bn = 64;
+  struct Cand {
+    int bm, bn;
+    double alpha, fixed;
+  };
+  const Cand cands[3] = {{128, 128, 0.0634, 6.7}, {128, 64, 0.0347, 1.8}, {64, 64, 0.0177, 1.0}};
+  const double K = (double)a.ntaps * a.Kc;
+  double best = 1e300;
+  for (const Cand& c : cands) {
+    if (c.bn == 128 && a.N <= 64) continue;
+    const long long rounds = (blocks(c.bm, c.bn) + 255) / 256;
+    const double t = (double)rounds * (c.alpha * K + c.fixed);
+    if (t < best * 0.995) {
+      best = t;
+      *bm = c.bm;
+      *bn = c.bn;
+    }
   }
 }
 
