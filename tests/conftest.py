@@ -3,6 +3,9 @@ import sys
 
 import numpy as np
 import pytest
+import torch  # noqa: F401  (before the oracle's first OpenMP region: on the GPU boxes the oracle's C kernels ran 20x
+#               slower per call when libgomp was first initialised by them rather than after torch's own start-up —
+#               `pytest tests/test_gpu_train_parity.py` alone took 5 minutes, the same tests 20 s in the full run)
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
