@@ -28,6 +28,73 @@ sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs @ 2.4 GHz
 HBM_PEAK_GBS = 8000.0
+ROCPROF = "/opt/rocm/bin/rocprofv3"
+
+
+def _short_kernel_name(name):
+    """kernel name without its trailing argument list"""
+    name = name.strip()
+    if not name.endswith(")"):
+        return name
+    depth = 0
+    for i in range(len(name) - 1, -1, -1):
+        depth += name[i] == ")"
+        depth -= name[i] == "("
+        if depth == 0:
+            return name[:i]
+    return name
+
+
+def measure_hbm_traffic(argv, steps_run):
+    """HBM traffic of this very command, measured now: two extra child runs of bench.py under
+    `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (separate passes, counters only, no tracing — the
+    recipe of MI355X_MICROARCH.md, section HBM), started BEFORE this process touches the GPU.  Counters are KiB per
+    dispatch; gfx950 tallies the 128-B read requests of wide coalesced loads at 64 B, so FETCH_SIZE is doubled;
+    WRITE_SIZE is taken as is.  Returns {kernel: {"launches", "fetch_bytes", "write_bytes", "hbm_bytes"}} per
+    LAUNCH (mean over the dispatches of the run), plus "_per_step" = bytes of all library kernels per step."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if not os.path.exists(ROCPROF):
+        return None, "rocprofv3 not found"
+    out = {}
+    tmp = tempfile.mkdtemp(prefix="vy_pmc_", dir="/tmp")
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, counter)
+            env = dict(os.environ, VY_BENCH_CHILD="1", TMPDIR="/tmp")
+            cmd = [ROCPROF, "--pmc", counter, "--output-format", "csv", "-d", d, "--", sys.executable,
+                   os.path.abspath(__file__)] + argv
+            p = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=900)
+            files = glob.glob(os.path.join(d, "*", "*counter_collection.csv"))
+            if p.returncode != 0 or not files:
+                return None, "rocprofv3 --pmc %s failed (rc %d): %s" % (counter, p.returncode, p.stderr.decode()[-300:])
+            agg, disp = {}, {}
+            for r in csv.DictReader(open(files[0])):
+                if r["Counter_Name"] != counter:
+                    continue
+                k = _short_kernel_name(r["Kernel_Name"])
+                agg[k] = agg.get(k, 0.0) + float(r["Counter_Value"])
+                disp.setdefault(k, set()).add(r["Dispatch_Id"])
+            for k, v in agg.items():
+                e = out.setdefault(k, {"launches": len(disp[k]), "fetch_bytes": 0.0, "write_bytes": 0.0})
+                if counter == "FETCH_SIZE":
+                    e["fetch_bytes"] = 2.0 * v * 1024.0 / len(disp[k])
+                else:
+                    e["write_bytes"] = v * 1024.0 / len(disp[k])
+    except Exception as e:  # the measurement is best effort: the bench line says so instead of failing
+        return None, "%s: %s" % (type(e).__name__, e)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    per_step = 0.0
+    for k, e in out.items():
+        e["hbm_bytes"] = e["fetch_bytes"] + e["write_bytes"]
+        if not (k.startswith("__amd_rocclr") or "at::native" in k):
+            per_step += e["hbm_bytes"] * e["launches"] / float(steps_run)
+    out["_per_step"] = per_step
+    return out, None
 
 
 def main():
@@ -50,6 +117,9 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL over xGMI)")
     ap.add_argument("--share-gpu", action="store_true",
                     help="testing only: all ranks use cuda:0 (with --backend gloo) to exercise the N>1 code path on one GPU")
+    ap.add_argument("--no-pmc", action="store_true",
+                    help="skip the two rocprofv3 --pmc child runs that measure roofline.traffic (N = 1 only)")
+    ap.add_argument("--no-latency", action="store_true", help="skip the batch-1 latency figure (N = 1 inference only)")
     args = ap.parse_args()
     # `python bench.py --gpus N` (no rank environment): this process only starts the N ranks and waits —
     # it never touches a GPU and never execs (videoyolo_amd/launch.py).  Under torch.distributed.run the
@@ -62,6 +132,15 @@ def main():
             args.size = 416
         if "--batch" not in " ".join(sys.argv):
             args.batch = 16
+    # roofline.traffic is MEASURED by this run (not read from a committed file): at N = 1 two child runs of the
+    # same workload under rocprofv3 --pmc, before this process touches the GPU
+    traffic, traffic_note = None, "not measured (--no-pmc / --no-roofline / N > 1)"
+    in_child = bool(os.environ.get("VY_BENCH_CHILD"))
+    if args.gpus == 1 and "WORLD_SIZE" not in os.environ and not in_child and not args.no_pmc and not args.no_roofline:
+        child = ["--mode", args.mode, "--size", str(args.size), "--batch", str(args.batch), "--classes",
+                 str(args.classes), "--obj-bias", str(args.obj_bias), "--steps", "2", "--warmup", "1",
+                 "--cpu-frames", "0", "--no-roofline", "--no-pmc", "--no-latency"]
+        traffic, traffic_note = measure_hbm_traffic(child, 3)
 
     import numpy as np
     import torch
@@ -93,7 +172,7 @@ def main():
     x = torch.randn((args.batch, 3, args.size, args.size), generator=g, dtype=torch.float32).to(dev)
 
     if args.mode == "train":
-        return bench_train(args, vy, net, x, dev, dist, rank, world)
+        return bench_train(args, vy, net, x, dev, dist, rank, world, traffic, traffic_note)
 
     def barrier():
         if dist is not None:
@@ -163,24 +242,44 @@ def main():
             "by_kernel_ms": {k: round(a[1], 4) for k, a in agg.items()},
         }
         result["roofline"]["algorithmic_bytes_per_launch_avg"] = by / n
-        # HBM bytes per launch of the same kernel from the committed rocprofv3 PMC passes of this command
-        # (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE; profiles/rNN_infer608_b64_pmc_hbm.json)
-        if (args.size, args.batch, args.classes) == (608, 64, 20):
-            import glob
-            pm = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_infer608_b64_pmc_hbm.json")))
-            if pm:
-                try:
-                    ks = json.load(open(pm[-1]))["kernels"]
-                    k = next((v for n, v in ks.items() if n.startswith("void conv_igemm_kernel<128, 128, 2, 2, false")), None)
-                    if k and dom == "conv_igemm_kernel<128x128>":
-                        result["roofline"]["traffic"] = k["hbm_MB_per_launch"] * 1e6
-                        result["roofline"]["traffic_source"] = os.path.basename(pm[-1])
-                except Exception:
-                    pass
+        # HBM bytes per launch of the same kernel, measured by this run's two rocprofv3 --pmc child passes
+        if traffic:
+            tile = dom.split("<")[1].rstrip(">").split("x")
+            key = next((k for k in traffic if k.startswith("void conv_igemm_kernel<%s, %s," % (tile[0], tile[1]))
+                        and k.rstrip(">").endswith("false")), None)
+            if key:
+                result["roofline"]["traffic"] = traffic[key]["hbm_bytes"]
+                result["roofline"]["traffic_detail"] = {
+                    "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child runs of this command (FETCH x2: gfx950)",
+                    "fetch_bytes_per_launch": traffic[key]["fetch_bytes"], "write_bytes_per_launch": traffic[key]["write_bytes"],
+                    "over_algorithmic": traffic[key]["hbm_bytes"] / (by / n),
+                    "whole_step_hbm_bytes": traffic["_per_step"],
+                    "other_kernels_MB_per_launch": {k[:48]: round(v["hbm_bytes"] / 1e6, 2) for k, v in traffic.items()
+                                                    if isinstance(v, dict) and k != key and "rocclr" not in k
+                                                    and "at::native" not in k}}
+        if result["roofline"]["traffic"] is None:
+            result["roofline"]["traffic_note"] = traffic_note
         tail = agg.get("decode_nms")
         if tail:
             result["roofline"]["decode_nms"] = {
                 "ms": tail[1], "algorithmic_GBps": tail[3] / (tail[1] * 1e-3) / 1e9, "hbm_peak_GBps": HBM_PEAK_GBS}
+
+    if rank == 0 and world == 1 and not args.no_latency:
+        # single-frame latency of the same path (the floor a video stream sees): eager and as a replayed HIP graph
+        lat = {}
+        x1 = x[:1].contiguous()
+        for label, hyb in (("eager", False), ("hip_graph", True)):
+            net.hybridize(hyb)
+            for _ in range(5):
+                net(x1)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(30):
+                net(x1)
+            torch.cuda.synchronize()
+            lat[label + "_ms"] = 1e3 * (time.perf_counter() - t0) / 30
+        net.hybridize(False)
+        result["latency_batch1"] = dict(lat, size=args.size, note="one frame resident in HBM -> 100 detection rows")
 
     if rank == 0 and world == 1 and args.cpu_frames > 0:
         # CPU baseline: the oracle (a port of the same algorithm; NOT the reference's MXNet path,
@@ -205,7 +304,7 @@ def main():
         dist.destroy_process_group()
 
 
-def bench_train(args, vy, net, x, dev, dist, rank, world):
+def bench_train(args, vy, net, x, dev, dist, rank, world, traffic=None, traffic_note=None):
     """BASELINE configs[2]/[4]: one step = recorded forward (batch-stat BN, targets, loss) + backward +
     gradient all-reduce (RCCL, bucketed and overlapped with backward) + SGD update."""
     import numpy as np
@@ -284,6 +383,16 @@ def bench_train(args, vy, net, x, dev, dist, rank, world):
             "kernel": "training step: conv_igemm (forward + dgrad) and wgrad_kernel; algorithmic FLOPs = 3 x forward",
             "forward_ms": fw, "backward_ms": bw, "allreduce_sgd_ms": up,
             "forward_tflops": fl / (fw * 1e-3) / 1e12, "backward_tflops": 2 * fl / (bw * 1e-3) / 1e12}
+        if traffic:
+            # HBM bytes of ONE training step, all library kernels (measured: see measure_hbm_traffic)
+            result["roofline"]["traffic"] = traffic["_per_step"]
+            top = sorted(((k, v) for k, v in traffic.items() if isinstance(v, dict) and "rocclr" not in k and "at::native" not in k),
+                         key=lambda kv: -kv[1]["hbm_bytes"] * kv[1]["launches"])[:8]
+            result["roofline"]["traffic_detail"] = {
+                "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child runs of this command (FETCH x2: gfx950); bytes per step",
+                "top_kernels_MB_per_step": {k[:56]: round(v["hbm_bytes"] * v["launches"] / 3.0 / 1e6, 1) for k, v in top}}
+        else:
+            result["roofline"]["traffic_note"] = traffic_note
     if rank == 0:
         print(json.dumps(result))
     if dist is not None:

@@ -153,10 +153,21 @@ int vy_stream_destroy(void* stream);
 /* Frame pre-processing in front of the path: (batch,H,W,3) uint8 HWC device
  * frames -> (batch,3,H,W) fp32 NCHW, y = (x/255 - mean[c]) / std[c] — mx.nd.image.to_tensor +
  * mx.nd.image.normalize at models/definitions/yolo/transforms.py:331-334.  mean3/std3 are host
- * pointers to 3 floats.  (The resize in front of it, transforms.py:325-327 imresize(interp=9), is
- * OpenCV's area/bicubic and is not part of this library: frames arrive at the network size.) */
+ * pointers to 3 floats.  Frames that are not at the network size yet: vy_preprocess_resize_frames below. */
 int vy_preprocess_frames(const uint8_t* frames_hwc, float* out_nchw, int32_t batch, int32_t height,
                          int32_t width, const float* mean3, const float* std3, void* stream);
+
+/* The whole YOLO3VideoInferenceTransform.__call__ (models/definitions/yolo/transforms.py:316-350) in one
+ * launch: (batch, src_height, src_width, 3) uint8 device frames -> resize to (height, width) as
+ * timage.imresize(frame, width, height, interp=9) does (:325-327: OpenCV INTER_AREA when both sides shrink,
+ * INTER_CUBIC when both grow, INTER_LINEAR otherwise, on uint8 with OpenCV's fixed-point / float arithmetic
+ * [UPSTREAM-RECALLED: gluoncv, mxnet and OpenCV are not available here; oracle/resize_oracle.py states the
+ * arithmetic and tests/test_resize_oracle.py cross-checks it against torch / exact area definitions]) -> the
+ * uint8 value the reference's resized NDArray would hold -> to_tensor + normalize -> (batch,3,height,width)
+ * fp32 NCHW.  The resized frame itself is never materialised.  Area shrink factors above 10 are rejected. */
+int vy_preprocess_resize_frames(const uint8_t* frames_hwc, int32_t src_height, int32_t src_width, float* out_nchw,
+                                int32_t batch, int32_t height, int32_t width, const float* mean3, const float* std3,
+                                void* stream);
 
 /* Prefetch target generation on the device: YOLOV3PrefetchTargetGenerator.forward,
  * models/definitions/yolo/yolo_target.py:31-148 (called per sample from the DataLoader transform,

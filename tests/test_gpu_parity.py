@@ -173,7 +173,7 @@ def test_preprocess_and_postprocess(voc_classes, synth20):
     assert x.shape == (3, 3, 96, 96)
     assert np.array_equal(x.cpu().numpy(), want)
     with pytest.raises(ValueError):
-        t(frames_u8[:, :64])
+        t(frames_u8[..., :2])                        # not 3 channels (other sizes are resized: test_gpu_resize.py)
     net = _net(voc_classes, synth20)
     ids, scores, bboxes = net(x)
     rows = transforms.postprocess(ids, scores, bboxes, 96)

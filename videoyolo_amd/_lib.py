@@ -62,6 +62,7 @@ SIGNATURES.update({
     "vy_stream_destroy": (ctypes.c_int, [_vp]),
     "vy_prefetch_targets": (ctypes.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "vy_preprocess_frames": (ctypes.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "vy_preprocess_resize_frames": (ctypes.c_int, [_vp, _i32, _i32, _vp, _i32, _i32, _i32, _vp, _vp, _vp]),
     "vy_net_train_workspace_bytes": (_sz, [_vp, _i32, _i32, _i32]),
     "vy_net_bind_train": (ctypes.c_int, [_vp, _vp, _sz, _i32, _i32, _i32, _vp, _vp, _vp]),
     "vy_net_set_train_options": (ctypes.c_int, [_vp, _f32, _i32]),

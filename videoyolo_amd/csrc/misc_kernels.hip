@@ -12,8 +12,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // matrix-core work: D[i = pixel][j = cout] = sum_k patch[i][k] * w[j][k] with k = (kh, kw, cin) padded
 // 27 -> 28, 14 x v_mfma_f32_32x32x2_f32 per 32 pixels.  The chain runs k ascending (k0 = 2s from lanes
 // 0-31, k1 = 2s+1 from lanes 32-63): the same fma order as the CPU checker's 3-channel conv.
-//   A operand: lane (pixel, h) reads the NCHW frame directly — 32 consecutive x of one image row
-//   (W % 32 == 0, so a 32-pixel tile never straddles rows): coalesced, L1/L2-resident re-reads;
+//   A operand: a block owns `rows` consecutive output rows of one frame; it first copies the 3 x (rows + 2)
+//   input rows they touch into LDS (16-B loads, zero halo rows / columns written explicitly), then every tap of
+//   every 32-pixel tile is a conflict-free ds_read_b32 — each input value leaves HBM/L2 once per block (round 1
+//   read the frame straight from global memory, 27 dword loads per pixel: FETCH_SIZE 15.8 x the input);
 //   B operand: this lane's 14 weights, loaded once per wave;
 //   output: lane (cout, h) holds 16 pixels of its channel -> every store writes two 128-B pixel vectors.
 // RAW (training): the raw conv goes to the z plane and the block's per-channel sum / sum of squares
@@ -21,70 +23,69 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // ---------------------------------------------------------------------------------------------
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int kStemTilesPerWave = 8;  // 32-pixel tiles per wave; block = 4 waves = 1024 pixels
+// rows per block: 2, or 1 for very wide frames (the strip must fit in LDS: 3 x (rows + 2) x (W + 8) floats)
+static int stem_rows(int W) { return 3 * 4 * (W + 8) * 4 <= 120 * 1024 ? 2 : 1; }
 
-int vy_stem_blocks(int B, int H, int W) {
-  const long long tiles = (long long)B * H * W / 32;
-  return (int)((tiles + 4 * kStemTilesPerWave - 1) / (4 * kStemTilesPerWave));
-}
+int vy_stem_blocks(int B, int H, int W) { return B * H / stem_rows(W); }
 
 template <bool RAW>
-__global__ __launch_bounds__(256) void stem_kernel(const StemArgs a, double* __restrict__ partials) {
+__global__ __launch_bounds__(256) void stem_kernel(const StemArgs a, double* __restrict__ partials, const int rows) {
 #if defined(__HIP_DEVICE_COMPILE__)
+  extern __shared__ __attribute__((aligned(16))) float strip[];  // [3][rows + 2][W + 8]: data at columns 4 .. W+3
   __shared__ double red[2][4][32];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: descriptors stay scalar
   const int lrow = lane & 31, h = lane >> 5;
-  constexpr unsigned kOob = 0x80000000u;  // beyond every descriptor's range: load returns 0, store is dropped
   constexpr int kRsrcFlags = 0x00020000;
-  // B operand and, for every k-step of this half-wave (k = 2s + h), the tap's element offset inside one
-  // frame relative to the centre pixel, plus bit masks of the steps whose tap looks up / down / left /
-  // right (they read zero padding on the matching image border)
+  const int Wp = a.W + 8, srows = rows + 2;
+  const int rpb = a.H / rows;                    // blocks per frame (H % 32 == 0, rows in {1, 2})
+  const int b = blockIdx.x / rpb, y0 = (blockIdx.x - b * rpb) * rows;
+  // ---- stage the input strip: rows y0-1 .. y0+rows of the three channels
+  {
+    const int w4 = a.W >> 2;
+    const int total = 3 * srows * w4;
+    for (int i = threadIdx.x; i < total; i += 256) {
+      const int q = i % w4, rr = (i / w4) % srows, c = i / (w4 * srows);
+      const int y = y0 - 1 + rr;
+      f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+      if (y >= 0 && y < a.H) v = *reinterpret_cast<const f32x4*>(a.x + (((long long)b * 3 + c) * a.H + y) * a.W + q * 4);
+      *reinterpret_cast<f32x4*>(strip + (c * srows + rr) * Wp + 4 + q * 4) = v;
+    }
+    for (int i = threadIdx.x; i < 3 * srows * 2; i += 256) {  // the zero columns left and right of every row
+      const int side = i & 1, rr = i >> 1;
+      strip[rr * Wp + (side ? a.W + 4 : 3)] = 0.0f;
+    }
+  }
+  // B operand and, for every k-step of this half-wave (k = 2s + h), the tap's element offset inside the strip
+  // relative to the pixel's position in strip row 1 of channel 0
   float bw[14];
-  int tap4[14];
-  unsigned m_up = 0, m_down = 0, m_left = 0, m_right = 0, m_pad = 0;
+  int tap[14];
 #pragma unroll
   for (int s = 0; s < 14; ++s) {
     const int k = 2 * s + h;
     const bool kv = k < 27;
     const int kk = kv ? k : 0;
     const int dy = kk / 9 - 1, dx = (kk / 3) % 3 - 1, c = kk % 3;
-    bw[s] = kv ? a.w[lrow * 27 + kk] : 0.0f;
-    tap4[s] = ((c * a.H + dy) * a.W + dx) * 4;
-    m_up |= (unsigned)(dy < 0) << s;
-    m_down |= (unsigned)(dy > 0) << s;
-    m_left |= (unsigned)(dx < 0) << s;
-    m_right |= (unsigned)(dx > 0) << s;
-    m_pad |= (unsigned)(!kv) << s;
+    bw[s] = kv ? a.w[lrow * 27 + kk] : 0.0f;  // the padded 28th k multiplies a zero weight
+    tap[s] = (c * srows + dy) * Wp + dx;
   }
   float sc = 1.0f, sh = 0.0f;
   if (!RAW) {
     sc = a.scale[lrow];
     sh = a.shift[lrow];
   }
+  __syncthreads();
   double s1 = 0.0, s2 = 0.0;
-  const long long tiles = (long long)a.B * a.H * a.W / 32;
   const int tiles_per_row = a.W / 32;
-  const long long t0 = ((long long)blockIdx.x * 4 + wave) * kStemTilesPerWave;
+  const int tiles = rows * tiles_per_row;
   const unsigned st_off = (unsigned)(lrow * 4 + h * 4 * 128);  // this lane's channel, pixel rows 4h.. of the tile
-  for (int q = 0; q < kStemTilesPerWave; ++q) {
-    const long long tile = t0 + q;
-    if (tile >= tiles) break;  // wave-uniform
-    const int x0 = (int)(tile % tiles_per_row) * 32;
-    const long long row = tile / tiles_per_row;
-    const int y = (int)(row % a.H), b = (int)(row / a.H);
-    const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(a.x) + (long long)b * 3 * a.H * a.W, 0, 3 * a.H * a.W * 4, kRsrcFlags);
-    const int x = x0 + lrow;
-    const unsigned bad = m_pad | (y == 0 ? m_up : 0u) | (y == a.H - 1 ? m_down : 0u) | (x == 0 ? m_left : 0u) |
-                         (x == a.W - 1 ? m_right : 0u);
-    const int centre4 = (y * a.W + x) * 4;
+  for (int tile = wave; tile < tiles; tile += 4) {  // wave-uniform
+    const int ry = tile / tiles_per_row, x0 = (tile - ry * tiles_per_row) * 32;
+    const int y = y0 + ry;
+    const float* centre = strip + (ry + 1) * Wp + 4 + x0 + lrow;
     float av[14];
 #pragma unroll
-    for (int s = 0; s < 14; ++s) {
-      const unsigned off = ((bad >> s) & 1u) ? kOob : (unsigned)(centre4 + tap4[s]);
-      av[s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(in_rsrc, off, 0, 0));
-    }
+    for (int s = 0; s < 14; ++s) av[s] = centre[tap[s]];
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
@@ -132,14 +133,28 @@ static hipError_t stem_check(const StemArgs& a) {
 
 hipError_t vy_launch_stem(const StemArgs& a, hipStream_t s) {
   if (stem_check(a) != hipSuccess) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(stem_kernel<false>, dim3(vy_stem_blocks(a.B, a.H, a.W)), dim3(256), 0, s, a, nullptr);
+  const int rows = stem_rows(a.W);
+  const size_t lds = (size_t)3 * (rows + 2) * (a.W + 8) * sizeof(float);
+  if (lds > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_kernel<false>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL(stem_kernel<false>, dim3(vy_stem_blocks(a.B, a.H, a.W)), dim3(256), lds, s, a, nullptr, rows);
   return hipGetLastError();
 }
 
 // training: raw conv -> z plane + partials[vy_stem_blocks][2][32] (double)
 hipError_t vy_launch_stem_raw(const StemArgs& a, double* partials, hipStream_t s) {
   if (stem_check(a) != hipSuccess) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(stem_kernel<true>, dim3(vy_stem_blocks(a.B, a.H, a.W)), dim3(256), 0, s, a, partials);
+  const int rows = stem_rows(a.W);
+  const size_t lds = (size_t)3 * (rows + 2) * (a.W + 8) * sizeof(float);
+  if (lds > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_kernel<true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL(stem_kernel<true>, dim3(vy_stem_blocks(a.B, a.H, a.W)), dim3(256), lds, s, a, partials, rows);
   return hipGetLastError();
 }
 

@@ -1,9 +1,10 @@
 """The steps either side of the model call in the reference's inference driver.
 
   before  YOLO3VideoInferenceTransform.__call__  models/definitions/yolo/transforms.py:316-350
-          (resize -> to_tensor -> normalize).  to_tensor + normalize run as one HIP kernel
-          (csrc/preproc.hip); the resize (mxnet imresize interp=9 = OpenCV area/bicubic) is not
-          reproduced — no OpenCV offline to pin it — so frames must already have the network size.
+          (resize -> to_tensor -> normalize) as ONE HIP kernel (csrc/preproc.hip): imresize(interp=9) =
+          OpenCV area (shrink) / bicubic (enlarge) / bilinear (mixed) on the uint8 frame, restated from memory
+          (no OpenCV offline: oracle/resize_oracle.py, cross-checked against torch / exact area definitions),
+          fused with to_tensor + normalize; frames already at the network size skip the resize.
   after   detect_yolo3.py:226 (clip to the image), :256-265 (drop id < 0 rows, boxes / image size,
           one [id, score, x1, y1, x2, y2] row per detection), :327-330 (the prediction txt line).
 """
@@ -24,8 +25,8 @@ class YOLO3VideoInferenceTransform(object):
         self._std = np.asarray(std, np.float32)
 
     def __call__(self, frames, device="cuda:0"):
-        """frames: (B,H,W,3) or (H,W,3) uint8 (numpy or torch) at the network size -> (B,3,H,W) fp32
-        normalised torch tensor on `device`."""
+        """frames: (B,h,w,3) or (h,w,3) uint8 (numpy or torch), any size -> (B,3,height,width) fp32 normalised
+        torch tensor on `device` (resized like timage.imresize(frame, width, height, interp=9))."""
         import torch
         lib = _lib.load()
         x = frames if isinstance(frames, torch.Tensor) else torch.as_tensor(np.ascontiguousarray(frames))
@@ -34,14 +35,13 @@ class YOLO3VideoInferenceTransform(object):
         if x.dim() == 3:
             x = x[None]
         b, h, w, c = x.shape
-        if c != 3 or (h, w) != (self._height, self._width):
-            raise ValueError("expected (B,%d,%d,3) frames, got %s (resize is outside this library)"
-                             % (self._height, self._width, tuple(x.shape)))
+        if c != 3:
+            raise ValueError("expected (B,h,w,3) frames, got %s" % (tuple(x.shape),))
         x = x.to(device).contiguous()
-        out = torch.empty((b, 3, h, w), dtype=torch.float32, device=x.device)
+        out = torch.empty((b, 3, self._height, self._width), dtype=torch.float32, device=x.device)
         with torch.cuda.device(x.device):
-            _lib.check(lib.vy_preprocess_frames(
-                ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(out.data_ptr()), b, h, w,
+            _lib.check(lib.vy_preprocess_resize_frames(
+                ctypes.c_void_p(x.data_ptr()), h, w, ctypes.c_void_p(out.data_ptr()), b, self._height, self._width,
                 self._mean.ctypes.data_as(ctypes.c_void_p), self._std.ctypes.data_as(ctypes.c_void_p),
                 ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)))
         return out
