@@ -11,16 +11,21 @@
 // and its sort key is (score, -r): box_nms orders by score descending and this implementation
 // breaks score ties by ascending r (a stable sort of the reference's tensor).
 //
-// Pipeline per batch (all images in parallel).  Pass 0 decodes every class score once from the 3 head
-// planes and keeps it ([B][C][anchors] fp32, 1.8 MB per image at 608/20 — a sixth of the reference's
-// candidate tensor, no boxes, no ids); the later passes and the collect read scores instead of paying
-// 1 + C sigmoids per anchor again:
-//   1. radix select of the k-th largest key, k = min(topk, #valid): pass 0 buckets the score
-//      linearly (1024 buckets, spreads LDS-atomic contention), passes 1-3 refine the score bits
-//      10 at a time inside the chosen bucket, passes 4-6 refine the inverted row index among
-//      candidates that tie with the k-th score.  A pass is skipped once the threshold is exact.
-//   2. collect the k candidates at or above the threshold, decoding their boxes.
-//   3. one workgroup per image: bitonic sort by key, greedy per-class IoU suppression,
+// Pipeline per batch (all images in parallel), five launches:
+//   1. hist (pass 0): decode every class score once from the 3 head planes, keep it ([B][C][anchors] fp32,
+//      1.8 MB per image at 608/20 — a sixth of the reference's candidate tensor, no boxes, no ids) and
+//      histogram it into 1024 linear score buckets;
+//   2. select (pass 0): the bucket holding the k-th largest key, k = min(topk, #valid);
+//   3. compact: one more sweep of the cached scores — candidates in HIGHER buckets are all wanted and go
+//      straight to the entry list (box decoded), candidates IN the bucket are appended to a small per-image
+//      list of keys (typically a few hundred of the 454 860);
+//   4. refine: one workgroup per image finishes the radix select on that list (passes 1-3 refine the score
+//      bits 10 at a time, passes 4-6 the inverted row index among candidates tying with the k-th score; a
+//      pass is skipped once the threshold is exact) and appends the list members at or above the threshold
+//      to the entries.  Only when the bucket overflows the list (degenerate inputs: every score equal) does
+//      this kernel walk the whole score cache instead.  (Round 1 swept all cached scores in each of the six
+//      refinement passes and once more to collect: 16 launches, 6x the bytes.)
+//   5. sort_nms: one workgroup per image: bitonic sort by key, greedy per-class IoU suppression,
 //      compaction, write the first post_nms rows (-1 filler).
 // HBM-bound integer/byte work: coalesced channel-contiguous reads, LDS histograms, no MFMA.
 #include "kernels.h"
@@ -41,8 +46,12 @@ struct SelState {
   int32_t k_eff;          // min(topk, nvalid)
   int32_t done;           // threshold exact: later passes are no-ops
   int32_t count;          // collect counter
-  int32_t pad[7];
+  int32_t bucket_n;       // candidates in the selected bucket
+  int32_t list_n;         // keys appended to the bucket list (== bucket_n unless it overflowed)
+  int32_t pad[5];
 };
+
+constexpr int kListCap = 16384;  // bucket-list capacity per image (keys of 8 B)
 
 struct Entry {
   uint32_t sbits, inv;
@@ -52,10 +61,11 @@ struct Entry {
 };
 
 struct Scratch {
-  // [B] SelState | [B][kBins] hist | [B][VY_NMS_MAX_TOPK] Entry | [B][C][n_items] score
+  // [B] SelState | [B][kBins] hist | [B][VY_NMS_MAX_TOPK] Entry | [B][kListCap] key | [B][C][n_items] score
   SelState* st;
   uint32_t* hist;
   Entry* ent;
+  unsigned long long* list;
   float* score;
 };
 
@@ -70,6 +80,8 @@ __host__ __device__ inline Scratch carve(void* base, int B) {
   p += align256(sizeof(uint32_t) * (size_t)B * kBins);
   s.ent = (Entry*)p;
   p += align256(sizeof(Entry) * (size_t)B * VY_NMS_MAX_TOPK);
+  s.list = (unsigned long long*)p;
+  p += align256(sizeof(unsigned long long) * (size_t)B * kListCap);
   s.score = (float*)p;
   return s;
 }
@@ -129,6 +141,7 @@ __device__ __forceinline__ uint32_t pass_digit(int pass, uint32_t bucket, uint32
   }
 }
 
+// pass 0 only: decode, cache, bucket histogram
 __global__ __launch_bounds__(kHistThreads) void hist_kernel(const DetArgs d, void* scratch, int pass, int n_items) {
   const int b = blockIdx.y;
   Scratch sc = carve(scratch, d.B);
@@ -210,7 +223,7 @@ __global__ __launch_bounds__(kBins) void select_kernel(const DetArgs d, void* sc
     st->k_rem = rem;
     const uint32_t dgt = (uint32_t)t;
     switch (pass) {
-      case 0: st->Tb = dgt; break;
+      case 0: st->Tb = dgt; st->bucket_n = (int32_t)mine; break;
       case 1: st->Ts |= dgt << 20; st->smask |= 1023u << 20; break;
       case 2: st->Ts |= dgt << 10; st->smask |= 1023u << 10; break;
       case 3: st->Ts |= dgt; st->smask |= 1023u; break;
@@ -238,13 +251,51 @@ __device__ __forceinline__ void decode_box(const DetArgs& d, const Item& im, flo
   y2 = cy + hh;
 }
 
-__global__ __launch_bounds__(kHistThreads) void collect_kernel(const DetArgs d, void* scratch, int n_items) {
+// candidate row r of image b -> its anchor item (for the box) and class
+__device__ __forceinline__ void locate_cand(const DetArgs& d, int b, uint32_t r, Item& im, int& c) {
+  int s = 2;
+  if (r < (uint32_t)d.head[1].cand_base)
+    s = 0;
+  else if (r < (uint32_t)d.head[2].cand_base)
+    s = 1;
+  const HeadView& hv = d.head[s];
+  const int n_s = hv.H * hv.W * 3;
+  const int rel = (int)r - hv.cand_base;
+  c = rel / n_s;
+  const int it = rel - c * n_s;
+  const int a = it % 3, cell = it / 3;
+  im.scale = s;
+  im.x = cell % hv.W;
+  im.y = cell / hv.W;
+  im.a = a;
+  im.cstride = n_s;
+  im.cand0 = hv.cand_base + it;
+  im.p = hv.pred + ((long long)(b * (hv.H + 2) + im.y + 1) * (hv.W + 2) + im.x + 1) * hv.cs + hv.co + a * (5 + d.C);
+}
+
+__device__ __forceinline__ void put_entry(const DetArgs& d, Entry* ent, SelState* stp, const Item& im, int c,
+                                          uint32_t sbits, uint32_t inv) {
+  const int slot = atomicAdd(&stp->count, 1);
+  if (slot >= VY_NMS_MAX_TOPK) return;
+  Entry e;
+  decode_box(d, im, e.x1, e.y1, e.x2, e.y2);
+  e.sbits = sbits;
+  e.inv = inv;
+  e.cls = (float)c;
+  e.pad = 0;
+  ent[slot] = e;
+}
+
+// sweep of the cached scores after pass 0: higher buckets -> entries, the selected bucket -> key list
+__global__ __launch_bounds__(kHistThreads) void compact_kernel(const DetArgs d, void* scratch, int n_items) {
   const int b = blockIdx.y;
   Scratch sc = carve(scratch, d.B);
   SelState* stp = sc.st + b;
-  const SelState st = *stp;
-  if (st.k_eff <= 0) return;
+  const uint32_t Tb = stp->Tb;
+  if (stp->k_eff <= 0) return;
+  const bool fits = stp->bucket_n <= kListCap;
   Entry* ent = sc.ent + (size_t)b * VY_NMS_MAX_TOPK;
+  unsigned long long* list = sc.list + (size_t)b * kListCap;
   const int base = blockIdx.x * (kHistThreads * kItemsPerThread);
 #pragma unroll 1
   for (int q = 0; q < kItemsPerThread; ++q) {
@@ -252,35 +303,110 @@ __global__ __launch_bounds__(kHistThreads) void collect_kernel(const DetArgs d, 
     Item im;
     if (it >= n_items || !locate(d, b, it, im)) continue;
     const float* cache = sc.score + (size_t)b * d.C * n_items + it;
-    bool have_box = false;
-    float x1 = 0, y1 = 0, x2 = 0, y2 = 0;
     for (int c = 0; c < d.C; ++c) {
       const float s = cache[(size_t)c * n_items];
       if (!(s > d.valid_thresh)) continue;
+      const uint32_t bucket = score_bucket(s);
+      if (bucket < Tb) continue;
       const uint32_t sbits = vy_f32_to_bits(s);
       const uint32_t inv = ((1u << kIdxBits) - 1u) - (uint32_t)(im.cand0 + c * im.cstride);
-      const uint32_t bucket = score_bucket(s);
-      const bool take = bucket > st.Tb ||
-                        (bucket == st.Tb && (sbits > st.Ts || (sbits == st.Ts && inv >= st.Ti)));
-      if (!take) continue;
-      if (!have_box) {
-        decode_box(d, im, x1, y1, x2, y2);
-        have_box = true;
-      }
-      const int slot = atomicAdd(&stp->count, 1);
-      if (slot < VY_NMS_MAX_TOPK) {
-        Entry e;
-        e.sbits = sbits;
-        e.inv = inv;
-        e.x1 = x1;
-        e.y1 = y1;
-        e.x2 = x2;
-        e.y2 = y2;
-        e.cls = (float)c;
-        e.pad = 0;
-        ent[slot] = e;
+      if (bucket > Tb) {
+        put_entry(d, ent, stp, im, c, sbits, inv);
+      } else if (fits) {
+        const int slot = atomicAdd(&stp->list_n, 1);
+        if (slot < kListCap) list[slot] = ((unsigned long long)sbits << 32) | inv;
       }
     }
+  }
+}
+
+// one workgroup per image: passes 1-6 of the radix select on the bucket list (or, if it overflowed, on the whole
+// score cache), then the list members at or above the exact threshold become entries
+__global__ __launch_bounds__(kBins) void refine_kernel(const DetArgs d, void* scratch, int n_items) {
+  const int b = blockIdx.x, t = threadIdx.x;
+  Scratch sc = carve(scratch, d.B);
+  SelState* stp = sc.st + b;
+  __shared__ SelState st;
+  __shared__ uint32_t hist[kBins];
+  __shared__ uint32_t suf[kBins];
+  if (t == 0) st = *stp;
+  __syncthreads();
+  if (st.k_eff <= 0) return;
+  const bool from_list = st.bucket_n <= kListCap;
+  const unsigned long long* list = sc.list + (size_t)b * kListCap;
+  const float* cache = sc.score + (size_t)b * d.C * n_items;
+  const int n = from_list ? st.bucket_n : d.C * n_items;
+  const int n0 = d.head[0].H * d.head[0].W * 3, n1 = d.head[1].H * d.head[1].W * 3;
+  // element idx of the source -> (in the bucket?, sbits, inv)
+  auto fetch = [&](int idx, uint32_t& sbits, uint32_t& inv) -> bool {
+    if (from_list) {
+      const unsigned long long k = list[idx];
+      sbits = (uint32_t)(k >> 32);
+      inv = (uint32_t)k;
+      return true;
+    }
+    const float s = cache[idx];
+    if (!(s > d.valid_thresh) || score_bucket(s) != st.Tb) return false;
+    const int c = idx / n_items, it = idx - c * n_items;
+    uint32_t r;
+    if (it < n0)
+      r = (uint32_t)(d.head[0].cand_base + c * n0 + it);
+    else if (it < n0 + n1)
+      r = (uint32_t)(d.head[1].cand_base + c * n1 + (it - n0));
+    else
+      r = (uint32_t)(d.head[2].cand_base + c * (n_items - n0 - n1) + (it - n0 - n1));
+    sbits = vy_f32_to_bits(s);
+    inv = ((1u << kIdxBits) - 1u) - r;
+    return true;
+  };
+  for (int pass = 1; pass < 7; ++pass) {
+    if (st.done) break;  // uniform
+    hist[t] = 0;
+    __syncthreads();
+    for (int idx = t; idx < n; idx += kBins) {
+      uint32_t sbits, inv;
+      if (!fetch(idx, sbits, inv)) continue;
+      if ((sbits & st.smask) != st.Ts || (inv & st.imask) != st.Ti) continue;
+      atomicAdd(&hist[pass_digit(pass, st.Tb, sbits, inv)], 1u);
+    }
+    __syncthreads();
+    const uint32_t mine = hist[t];
+    suf[t] = mine;
+    __syncthreads();
+    for (int off = 1; off < kBins; off <<= 1) {
+      const uint32_t add = (t + off < kBins) ? suf[t + off] : 0u;
+      __syncthreads();
+      suf[t] += add;
+      __syncthreads();
+    }
+    const int k_rem = st.k_rem;
+    const uint32_t above = (t + 1 < kBins) ? suf[t + 1] : 0u;
+    __syncthreads();
+    if (k_rem > 0 && above < (uint32_t)k_rem && (uint32_t)k_rem <= above + mine) {
+      st.k_rem = k_rem - (int)above;
+      const uint32_t dgt = (uint32_t)t;
+      switch (pass) {
+        case 1: st.Ts |= dgt << 20; st.smask |= 1023u << 20; break;
+        case 2: st.Ts |= dgt << 10; st.smask |= 1023u << 10; break;
+        case 3: st.Ts |= dgt; st.smask |= 1023u; break;
+        case 4: st.Ti |= dgt << 20; st.imask |= 1023u << 20; break;
+        case 5: st.Ti |= dgt << 10; st.imask |= 1023u << 10; break;
+        default: st.Ti |= dgt; st.imask |= 1023u; break;
+      }
+      if ((uint32_t)(k_rem - (int)above) == mine || pass == 6) st.done = 1;
+    }
+    __syncthreads();
+  }
+  // the bucket's members at or above the threshold
+  Entry* ent = sc.ent + (size_t)b * VY_NMS_MAX_TOPK;
+  for (int idx = t; idx < n; idx += kBins) {
+    uint32_t sbits, inv;
+    if (!fetch(idx, sbits, inv)) continue;
+    if (!(sbits > st.Ts || (sbits == st.Ts && inv >= st.Ti))) continue;
+    Item im;
+    int c;
+    locate_cand(d, b, ((1u << kIdxBits) - 1u) - inv, im, c);
+    put_entry(d, ent, stp, im, c, sbits, inv);
   }
 }
 
@@ -661,7 +787,8 @@ hipError_t vy_launch_raw_detections(const DetArgs& a, float* ids, float* scores,
 
 size_t vy_det_scratch_bytes(int B, int n_items, int C) {
   return align256(sizeof(SelState) * (size_t)B) + align256(sizeof(uint32_t) * (size_t)B * kBins) +
-         align256(sizeof(Entry) * (size_t)B * VY_NMS_MAX_TOPK) + align256(sizeof(float) * (size_t)B * C * n_items);
+         align256(sizeof(Entry) * (size_t)B * VY_NMS_MAX_TOPK) +
+         align256(sizeof(unsigned long long) * (size_t)B * kListCap) + align256(sizeof(float) * (size_t)B * C * n_items);
 }
 
 hipError_t vy_launch_detect(const DetArgs& a, void* scratch, float* ids, float* scores, float* bboxes,
@@ -685,11 +812,10 @@ hipError_t vy_launch_detect(const DetArgs& a, void* scratch, float* ids, float* 
                        bboxes, keep_idx);
     return hipGetLastError();
   }
-  for (int pass = 0; pass < 7; ++pass) {
-    hipLaunchKernelGGL(hist_kernel, grid, dim3(kHistThreads), 0, s, a, scratch, pass, n_items);
-    hipLaunchKernelGGL(select_kernel, dim3(a.B), dim3(kBins), 0, s, a, scratch, pass);
-  }
-  hipLaunchKernelGGL(collect_kernel, grid, dim3(kHistThreads), 0, s, a, scratch, n_items);
+  hipLaunchKernelGGL(hist_kernel, grid, dim3(kHistThreads), 0, s, a, scratch, 0, n_items);
+  hipLaunchKernelGGL(select_kernel, dim3(a.B), dim3(kBins), 0, s, a, scratch, 0);
+  hipLaunchKernelGGL(compact_kernel, grid, dim3(kHistThreads), 0, s, a, scratch, n_items);
+  hipLaunchKernelGGL(refine_kernel, dim3(a.B), dim3(kBins), 0, s, a, scratch, n_items);
   hipLaunchKernelGGL(sort_nms_kernel, dim3(a.B), dim3(kNmsThreads), 0, s, a, scratch, rows, ids, scores, bboxes,
                      keep_idx);
   return hipGetLastError();
