@@ -149,3 +149,40 @@ def test_training_full_size_step():
     scale = before.abs()[mask].clamp_min(1e-3)
     assert float((diff / scale).max().item()) < 1e-5, "SGD update deviates from w - lr*(g/B + wd*w)"
     assert torch.equal(wp[~mask], before[~mask]), "non-trainable slots (running stats, padding) must not move"
+
+
+def test_training_step_at_416_against_the_oracle():
+    """One recorded step at the configs[2] frame size (416 x 416, VOC classes, 2 frames — what the CPU oracle
+    finishes in about half a minute on the host cores): the four losses per sample at 1e-4 and EVERY parameter
+    gradient within 2e-3 of its tensor's maximum, against the oracle's hand-derived backward — the full-size
+    counterpart of tests/test_gpu_train_parity.py (which stops at 96 x 96)."""
+    import videoyolo_amd as vy
+    from videoyolo_amd import autograd, init
+    from oracle import targets_oracle as T
+    from oracle import yolo3_oracle as O
+    from oracle import yolo3_train_oracle as TO
+    C, B, S = 20, 2, 416
+    params = init.synthetic_params(O.param_shapes(C), seed=233)
+    x = frames(B, S, seed=3)
+    gt, gid = T.synthetic_gt(B, S, C, m=8, seed=1, pad_to=10)
+    tg = T.prefetch_targets(C, S, S, gt, gid)
+    orc = TO.OracleYolo3Train(C, dict(params))
+    ref_losses = orc.forward_train(x, gt, *tg)
+    ref_grads = orc.backward()
+    net = vy.yolo3_darknet53(["c%d" % i for i in range(C)], pretrained_base=False)
+    net.set_parameters(params)
+    net.collect_params().reset_ctx("cuda:0")
+    with autograd.record():
+        losses = net(x, gt, *tg)
+        autograd.backward(losses)
+    for got, want in zip(losses, ref_losses):
+        np.testing.assert_allclose(got.cpu().numpy(), want, rtol=1e-4, atol=1e-4)
+    worst = ("", 0.0)
+    for name, want in ref_grads.items():
+        got = net.grad(name)
+        err = np.abs(got - want).max() / (np.abs(want).max() + 1e-6)
+        if err > worst[1]:
+            worst = (name, err)
+        assert err < 2e-3, (name, err)
+    assert len(ref_grads) == 219
+    print("416 x 416: worst gradient mismatch", worst)
