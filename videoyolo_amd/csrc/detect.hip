@@ -141,39 +141,59 @@ __device__ __forceinline__ uint32_t pass_digit(int pass, uint32_t bucket, uint32
   }
 }
 
-// pass 0 only: decode, cache, bucket histogram
+// Pass 0: decode every class score, keep it, histogram it into the 1024 linear buckets.
+// A block owns kPx consecutive pixels of ONE head of one image: their prediction vectors (kPx x cs floats,
+// contiguous inside an image row of the padded plane) are copied to LDS with 16-B loads — every 128-B line of the
+// head planes leaves HBM once — and decoded from there: objectness once per anchor, then one thread per
+// (class, anchor), so that consecutive lanes write consecutive floats of the score cache.  (Round 1 / the first
+// version of this round had one thread walk an anchor's 5 + C values in global memory: 4-byte loads at a 100-B
+// stride, FETCH_SIZE 1.7 GB per batch for 0.2 GB of head planes.)
+constexpr int kPx = 32;               // pixels per block
+constexpr int kMaxCs = 256;           // channel stride of a prediction plane: 3 * (5 + C) rounded up to 32, C <= 80
+
+__host__ __device__ inline int hist_blocks_of(int hw) { return (hw + kPx - 1) / kPx; }
+
 __global__ __launch_bounds__(kHistThreads) void hist_kernel(const DetArgs d, void* scratch, int pass, int n_items) {
   const int b = blockIdx.y;
   Scratch sc = carve(scratch, d.B);
-  const SelState st = sc.st[b];
-  if (st.done) return;
+  __shared__ __attribute__((aligned(16))) float tile[kPx * kMaxCs];
+  __shared__ float conf[kPx * 3];
   __shared__ uint32_t lh[kBins];
-  for (int i = threadIdx.x; i < kBins; i += kHistThreads) lh[i] = 0;
-  __syncthreads();
-  const int base = blockIdx.x * (kHistThreads * kItemsPerThread);
-#pragma unroll 1
-  for (int q = 0; q < kItemsPerThread; ++q) {
-    const int it = base + q * kHistThreads + threadIdx.x;
-    Item im;
-    if (it >= n_items || !locate(d, b, it, im)) continue;
-    float* cache = sc.score + (size_t)b * d.C * n_items + it;  // [c][item]: coalesced across the block
-    const float conf = pass == 0 ? vy_sigmoidf(im.p[4]) : 0.0f;
-    for (int c = 0; c < d.C; ++c) {
-      float s;
-      if (pass == 0) {
-        s = vy_sigmoidf(im.p[5 + c]) * conf;
-        cache[(size_t)c * n_items] = s;
-      } else {
-        s = cache[(size_t)c * n_items];
-      }
-      if (!(s > d.valid_thresh)) continue;
-      const uint32_t sbits = vy_f32_to_bits(s);
-      const uint32_t inv = ((1u << kIdxBits) - 1u) - (uint32_t)(im.cand0 + c * im.cstride);
-      const uint32_t bucket = score_bucket(s);
-      if (!prefix_match(st, pass, bucket, sbits, inv)) continue;
-      atomicAdd(&lh[pass_digit(pass, bucket, sbits, inv)], 1u);
-    }
+  // which head, which pixels
+  int blk = blockIdx.x, s = 0, item0 = 0;
+#pragma unroll
+  for (; s < 3; ++s) {
+    const int nb = hist_blocks_of(d.head[s].H * d.head[s].W);
+    if (blk < nb) break;
+    blk -= nb;
+    item0 += d.head[s].H * d.head[s].W * 3;
   }
+  if (s == 3) return;
+  const HeadView& hv = d.head[s];
+  const int hw = hv.H * hv.W, p0 = blk * kPx;
+  const int npx = hw - p0 < kPx ? hw - p0 : kPx;
+  const int cs4 = hv.cs >> 2;
+  for (int i = threadIdx.x; i < kBins; i += kHistThreads) lh[i] = 0;
+  for (int e = threadIdx.x; e < npx * cs4; e += kHistThreads) {
+    const int px = e / cs4, q = e - px * cs4;
+    const int p = p0 + px, x = p % hv.W, y = p / hv.W;
+    const float4 v = *reinterpret_cast<const float4*>(
+        hv.pred + ((long long)(b * (hv.H + 2) + y + 1) * (hv.W + 2) + x + 1) * hv.cs + hv.co + q * 4);
+    *reinterpret_cast<float4*>(tile + px * hv.cs + q * 4) = v;
+  }
+  __syncthreads();
+  const int P = 5 + d.C, nit = npx * 3;
+  for (int i = threadIdx.x; i < nit; i += kHistThreads) conf[i] = vy_sigmoidf(tile[(i / 3) * hv.cs + (i % 3) * P + 4]);
+  __syncthreads();
+  float* cache = sc.score + (size_t)b * d.C * n_items + item0 + p0 * 3;
+  const int cstride = hw * 3;
+  for (int idx = threadIdx.x; idx < nit * d.C; idx += kHistThreads) {
+    const int c = idx / nit, i = idx - c * nit;  // i = pixel * 3 + anchor inside the block: the candidate order
+    const float sv = vy_sigmoidf(tile[(i / 3) * hv.cs + (i % 3) * P + 5 + c]) * conf[i];
+    cache[(size_t)c * n_items + i] = sv;
+    if (sv > d.valid_thresh) atomicAdd(&lh[score_bucket(sv)], 1u);
+  }
+  (void)cstride;
   __syncthreads();
   uint32_t* gh = sc.hist + (size_t)b * kBins;
   for (int i = threadIdx.x; i < kBins; i += kHistThreads) {
@@ -838,13 +858,19 @@ hipError_t vy_launch_detect(const DetArgs& a, void* scratch, float* ids, float* 
   for (int i = 0; i < 3; ++i) n_items += a.head[i].H * a.head[i].W * 3;
   const int per_block = kHistThreads * kItemsPerThread;
   dim3 grid((n_items + per_block - 1) / per_block, a.B);
+  int hblocks = 0;
+  for (int i = 0; i < 3; ++i) {
+    hblocks += hist_blocks_of(a.head[i].H * a.head[i].W);
+    if (a.head[i].cs > kMaxCs || (a.head[i].cs & 3) || (a.head[i].co & 3)) return hipErrorInvalidValue;
+  }
+  const dim3 hgrid(hblocks, a.B);
   if (a.topk <= 0) {  // every valid candidate goes through NMS: pass 0 only fills the score cache
-    hipLaunchKernelGGL(hist_kernel, grid, dim3(kHistThreads), 0, s, a, scratch, 0, n_items);
+    hipLaunchKernelGGL(hist_kernel, hgrid, dim3(kHistThreads), 0, s, a, scratch, 0, n_items);
     hipLaunchKernelGGL(nms_all_kernel, dim3(a.B), dim3(kAllThreads), 0, s, a, scratch, n_items, rows, ids, scores,
                        bboxes, keep_idx);
     return hipGetLastError();
   }
-  hipLaunchKernelGGL(hist_kernel, grid, dim3(kHistThreads), 0, s, a, scratch, 0, n_items);
+  hipLaunchKernelGGL(hist_kernel, hgrid, dim3(kHistThreads), 0, s, a, scratch, 0, n_items);
   hipLaunchKernelGGL(select_kernel, dim3(a.B), dim3(kBins), 0, s, a, scratch, 0);
   hipLaunchKernelGGL(compact_kernel, grid, dim3(kHistThreads), 0, s, a, scratch, n_items);
   hipLaunchKernelGGL(refine_kernel, dim3(a.B), dim3(kBins), 0, s, a, scratch, n_items);
