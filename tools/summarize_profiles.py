@@ -8,9 +8,9 @@ G, P = os.path.join(R, "gpurun_out"), os.path.join(R, "profiles")
 
 
 def one(pattern):
-    f = glob.glob(os.path.join(G, pattern))
-    assert len(f) == 1, (pattern, f)
-    return f[0]
+    f = sorted(glob.glob(os.path.join(G, pattern)), key=os.path.getmtime)
+    assert f, pattern
+    return f[-1]  # the newest run of that pass
 
 
 def short(name):

@@ -46,7 +46,7 @@ __global__ __launch_bounds__(256) void to_tensor_normalize_kernel(const uint8_t*
 // cv::resize on the uint8 HWC frame [UPSTREAM-RECALLED: neither library is vendored or installable here]:
 //   both sides enlarged -> INTER_CUBIC, both shrunk -> INTER_AREA, anything else -> INTER_LINEAR,
 // each with OpenCV's 8-bit arithmetic (11-bit fixed-point weights for LINEAR / CUBIC, float pixel-area weights
-// for AREA; oracle/resize_oracle.py states every rounding step and is what the tests compare with, bit for bit).
+// for AREA; the CPU checker states every rounding step and is what the tests compare with, bit for bit).
 // The resized value is rounded to uint8 exactly where the reference's uint8 NDArray would hold it, then
 // (v / 255 - mean) / std goes straight to the NCHW plane: the resized frame is never written to memory.
 // One thread per destination pixel (3 channels); tables are recomputed per thread from (dx, dy) — they are a few

@@ -3,7 +3,7 @@
   before  YOLO3VideoInferenceTransform.__call__  models/definitions/yolo/transforms.py:316-350
           (resize -> to_tensor -> normalize) as ONE HIP kernel (csrc/preproc.hip): imresize(interp=9) =
           OpenCV area (shrink) / bicubic (enlarge) / bilinear (mixed) on the uint8 frame, restated from memory
-          (no OpenCV offline: oracle/resize_oracle.py, cross-checked against torch / exact area definitions),
+          (no OpenCV offline: the CPU checker restates every rounding step and is cross-checked against torch / exact area definitions),
           fused with to_tensor + normalize; frames already at the network size skip the resize.
   after   detect_yolo3.py:226 (clip to the image), :256-265 (drop id < 0 rows, boxes / image size,
           one [id, score, x1, y1, x2, y2] row per detection), :327-330 (the prediction txt line).
