@@ -111,7 +111,8 @@ def test_nms_settings_and_30_classes():
         np.testing.assert_allclose(scores, r[1], rtol=0, atol=TOL)
 
 
-@pytest.mark.parametrize("ncls,batch,size", [(1, 3, 64), (80, 2, 96), (3, 5, 128)])
+# (200, 1, 64): prediction vectors of 615 -> 640 floats: the decode pass stages 12 instead of 32 pixels per block
+@pytest.mark.parametrize("ncls,batch,size", [(1, 3, 64), (80, 2, 96), (3, 5, 128), (200, 1, 64)])
 def test_class_counts_and_odd_batches(ncls, batch, size):
     """1 class (18 prediction channels), 80 classes (255, COCO) and odd batch sizes: head tensors,
     kept-row indices, ids, scores and boxes against the oracle."""

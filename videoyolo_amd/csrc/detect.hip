@@ -148,28 +148,33 @@ __device__ __forceinline__ uint32_t pass_digit(int pass, uint32_t bucket, uint32
 // (class, anchor), so that consecutive lanes write consecutive floats of the score cache.  (Round 1 / the first
 // version of this round had one thread walk an anchor's 5 + C values in global memory: 4-byte loads at a 100-B
 // stride, FETCH_SIZE 1.7 GB per batch for 0.2 GB of head planes.)
-constexpr int kPx = 32;               // pixels per block
-constexpr int kMaxCs = 256;           // channel stride of a prediction plane: 3 * (5 + C) rounded up to 32, C <= 80
+constexpr int kPxMax = 32;            // pixels per block (fewer when the prediction vectors are very wide)
+constexpr int kTileFloats = 8192;     // LDS copy: kPx * cs floats; cs = 3 * (5 + C) rounded up to 32 (96 for VOC)
 
-__host__ __device__ inline int hist_blocks_of(int hw) { return (hw + kPx - 1) / kPx; }
+__host__ __device__ inline int hist_px(int cs) {
+  const int p = kTileFloats / cs;
+  return p > kPxMax ? kPxMax : (p < 1 ? 1 : p);
+}
+__host__ __device__ inline int hist_blocks_of(int hw, int cs) { return (hw + hist_px(cs) - 1) / hist_px(cs); }
 
 __global__ __launch_bounds__(kHistThreads) void hist_kernel(const DetArgs d, void* scratch, int pass, int n_items) {
   const int b = blockIdx.y;
   Scratch sc = carve(scratch, d.B);
-  __shared__ __attribute__((aligned(16))) float tile[kPx * kMaxCs];
-  __shared__ float conf[kPx * 3];
+  __shared__ __attribute__((aligned(16))) float tile[kTileFloats];
+  __shared__ float conf[kPxMax * 3];
   __shared__ uint32_t lh[kBins];
   // which head, which pixels
   int blk = blockIdx.x, s = 0, item0 = 0;
 #pragma unroll
   for (; s < 3; ++s) {
-    const int nb = hist_blocks_of(d.head[s].H * d.head[s].W);
+    const int nb = hist_blocks_of(d.head[s].H * d.head[s].W, d.head[s].cs);
     if (blk < nb) break;
     blk -= nb;
     item0 += d.head[s].H * d.head[s].W * 3;
   }
   if (s == 3) return;
   const HeadView& hv = d.head[s];
+  const int kPx = hist_px(hv.cs);
   const int hw = hv.H * hv.W, p0 = blk * kPx;
   const int npx = hw - p0 < kPx ? hw - p0 : kPx;
   const int cs4 = hv.cs >> 2;
@@ -860,8 +865,8 @@ hipError_t vy_launch_detect(const DetArgs& a, void* scratch, float* ids, float* 
   dim3 grid((n_items + per_block - 1) / per_block, a.B);
   int hblocks = 0;
   for (int i = 0; i < 3; ++i) {
-    hblocks += hist_blocks_of(a.head[i].H * a.head[i].W);
-    if (a.head[i].cs > kMaxCs || (a.head[i].cs & 3) || (a.head[i].co & 3)) return hipErrorInvalidValue;
+    hblocks += hist_blocks_of(a.head[i].H * a.head[i].W, a.head[i].cs);
+    if (a.head[i].cs > kTileFloats || (a.head[i].cs & 3) || (a.head[i].co & 3)) return hipErrorInvalidValue;
   }
   const dim3 hgrid(hblocks, a.B);
   if (a.topk <= 0) {  // every valid candidate goes through NMS: pass 0 only fills the score cache

@@ -163,17 +163,31 @@ size_t train_plan(vy_net* net, int b, int h, int w, bool commit) {
     if (!c.is_stem) {
       const int Ntot = c.k * c.k * c.cin;
       const int tiles = ((c.cout + 127) / 128) * ((Ntot + 127) / 128);
-      // Split-K over the pixels so that the launch has >= ~1024 blocks (2 rounds of the 512 resident ones):
-      // the weight gradients run beside the dgrad / BatchNorm chain, where many short blocks fill the gaps
-      // better than a launch sized to whole rounds (measured: 404 vs 401 frames/s); a split is >= 256 pixels
-      long long sp = (1024 + tiles - 1) / tiles;
-      const long long maxsp = (M + 255) / 256;
-      if (sp > maxsp) sp = maxsp;
-      if (sp < 1) sp = 1;
-      const long long k = ((M + sp - 1) / sp + 31) / 32 * 32;
-      sp = (M + k - 1) / k;
+      // Split-K over the pixels.  A block runs k_per_split / 32 k-steps (+ ~3 k-steps worth of prologue and slab
+      // store); the chip holds 512 blocks at a time (2 per CU), so the launch costs about
+      // ceil(tiles * splits / 512) * (k_per_split / 32 + 3).  Round 1 took the smallest split count with >= 1024
+      // blocks, which for the three big 3x3 groups lands just past a multiple of 512 (18 x 57 = 1026,
+      // 72 x 15 = 1080, 288 x 4 = 1152 blocks): a last round of a few blocks with the chip idle around them.  Now the
+      // cheapest (splits, k_per_split) under that model is taken; a split is >= 256 pixels.
+      long long best_k = ((M + 31) / 32) * 32, best_sp = 1;
+      double best_cost = 1e300;
+      for (long long k = 256; k <= ((M + 31) / 32) * 32; k += 32) {
+        const long long sp_k = (M + k - 1) / k;
+        const long long rounds = (tiles * sp_k + 511) / 512;
+        const double cost = (double)rounds * ((double)k / 32.0 + 3.0);
+        if (cost < best_cost) {
+          best_cost = cost;
+          best_k = k;
+          best_sp = sp_k;
+        }
+      }
+      if (M < 256) {
+        best_k = ((M + 31) / 32) * 32;
+        best_sp = 1;
+      }
+      const long long sp = best_sp;
       splits[i] = (int)sp;
-      kps[i] = (int)k;
+      kps[i] = (int)best_k;
       const size_t sl = (size_t)sp * c.cout * Ntot;
       if (sl > slab) slab = sl;
     }
