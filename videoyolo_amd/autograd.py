@@ -27,8 +27,10 @@ def is_training():
 def _scope(recording, training):
     s = _get()
     prev = (s.recording, s.training)
-    if recording and not s.recording:
-        s.tape = []  # a fresh recording: forwards recorded earlier and never back-propagated are dropped
+    depth = getattr(s, "depth", 0)
+    if recording and depth == 0:
+        s.tape = []  # an outermost record(): forwards recorded earlier and never back-propagated are dropped
+    s.depth = depth + 1
     if recording is not None:
         s.recording = recording
     if training is not None:
@@ -37,6 +39,7 @@ def _scope(recording, training):
         yield
     finally:
         s.recording, s.training = prev
+        s.depth = depth
 
 
 def record(train_mode=True):
