@@ -146,7 +146,6 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_kernel(const ConvA
   // LDS-DMA sources: wave-uniform base (advanced per k-step by the uniform tap / k offset) + per-lane 32-bit byte
   // offset relative to the tile's first row (rows ascend in memory, a tile spans less than one image plane)
   unsigned a_voff[A_INSTR];
-  const float* b_src[B_INSTR];
   unsigned b_voff[B_INSTR];
   const long long in_off0 = in_off[0];
   const float* a_sbase;
@@ -170,7 +169,6 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_kernel(const ConvA
       const int chunk = (lane & 7) ^ ((row >> 1) & 7);
       int n = n0 + row;
       n = n < a.N ? n : a.N - 1;
-      b_src[j] = nullptr;
       b_voff[j] = (unsigned)((n - n0) * wK * 4 + chunk * 16);  // relative to the tile's first weight row
       b_krow[j] = 0;
     } else {
@@ -179,8 +177,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_kernel(const ConvA
       const int row = (j * NW + wave) * RPI + lane / CPR;
       int n = n0 + (lane % CPR) * 4;
       n = n < a.N ? n : 0;
-      b_src[j] = a.w + n;
-      b_voff[j] = 0;
+      (void)n;
+      b_voff[j] = 0;  // set below (needs the tap / channel-chunk geometry)
       b_krow[j] = row;
     }
   }
@@ -207,7 +205,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_kernel(const ConvA
   int a_koff = 0;          // floats; |(dy * Wp + dx) * cs| < 2^23: 32-bit scalar arithmetic
   long long b_koff = 0;
   bool n_lastcc = false;
-  const float* b_sbase = a.w + (long long)n0 * wK;  // forward: the tile's first weight row (kernel argument + uniform)
+  // forward: the tile's first weight row; dgrad: the tensor itself (kernel argument + uniform values: scalar)
+  const float* b_sbase = DGRAD ? a.w : a.w + (long long)n0 * wK;
   auto advance = [&]() {
     const int tdy = (int)((a.pk_dy >> (2 * n_tap)) & 3u) - 1, tdx = (int)((a.pk_dx >> (2 * n_tap)) & 3u) - 1;
     const int tw = (int)((a.pk_w >> (4 * n_tap)) & 15ull);
@@ -222,14 +221,23 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_kernel(const ConvA
       ++n_tap;
     }
   };
-  long long b_row[B_INSTR], b_row_last[B_INSTR];
+  // dgrad: W is the [k = cout][n = cin] operand; lane offset = its k-row and n chunk, constant over the k-loop
+  // except in the last channel chunk of a cout that is not a multiple of 32 (the prediction convs: rows past
+  // cout re-read the last one) — a second offset set, chosen per DMA by a select on a scalar condition
+  unsigned b_voff_last[B_INSTR];
+  if (DGRAD) {
 #pragma unroll
-  for (int j = 0; j < B_INSTR; ++j) {
-    b_row[j] = (long long)b_krow[j] * a.w_taps * a.w_cin;
-    int o = (cchunks - 1) * 32 + b_krow[j];
-    o = o < a.w_cout ? o : a.w_cout - 1;
-    b_row_last[j] = (long long)(o - (cchunks - 1) * 32) * a.w_taps * a.w_cin;
+    for (int j = 0; j < B_INSTR; ++j) {
+      constexpr int CPR = BN / 4;
+      int n = n0 + (lane % CPR) * 4;
+      n = n < a.N ? n : 0;
+      b_voff[j] = (unsigned)((n + b_krow[j] * a.w_taps * a.w_cin) * 4);
+      int o = (cchunks - 1) * 32 + b_krow[j];
+      o = o < a.w_cout ? o : a.w_cout - 1;
+      b_voff_last[j] = (unsigned)((n + (o - (cchunks - 1) * 32) * a.w_taps * a.w_cin) * 4);
+    }
   }
+  const bool ragged_cout = DGRAD && (a.w_cout & 31) != 0;
   // DMA instruction idx (A: 0..A_INSTR-1, W: A_INSTR..) goes behind MFMA group idx*3/total: groups 0-2
   // carry everything, group 3 nothing, so the last DMA has a whole group (>= 16 MFMAs) to land before
   // the tile-end vmcnt(0)
@@ -243,19 +251,22 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_kernel(const ConvA
 #pragma unroll
     for (int j = 0; j < B_INSTR; ++j) {
       if (!(part < 0 || ((A_INSTR + j) * DMA_GROUPS) / DMA_TOTAL == part)) continue;
-      if (DGRAD)
-        lds_dma16(b_src[j] + b_koff + (n_lastcc ? b_row_last[j] : b_row[j]), lds0 + buf * STAGE + A_BYTES + (j * NW + wave) * 1024);
-      else
-        lds_dma16_s(b_voff[j], b_sbase + b_koff, lds0 + buf * STAGE + A_BYTES + (j * NW + wave) * 1024);
+      // (a select on a scalar condition, not a branch: control flow inside the unrolled body made hipcc copy the
+      // 64 accumulator registers between basic blocks)
+      const unsigned voff = (DGRAD && ragged_cout && n_lastcc) ? b_voff_last[j] : b_voff[j];
+      lds_dma16_s(voff, b_sbase + b_koff, lds0 + buf * STAGE + A_BYTES + (j * NW + wave) * 1024);
     }
   };
-  auto ktile = [&](int t, auto prefetch) {
+  // `parity` (which half of the double buffer holds this tile) is a compile-time constant: the k-loop is unrolled by
+  // two, so the buffer offset folds into the ds_read immediates instead of one vector add per fragment read
+  auto ktile = [&](auto parity, auto prefetch) {
     constexpr bool PREFETCH = decltype(prefetch)::value;
+    constexpr int PAR = decltype(parity)::value;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (PREFETCH) advance();
-    const int nbuf = (t + 1) & 1;
-    const unsigned char* sA = smem + (t & 1) * STAGE;
+    constexpr int nbuf = PAR ^ 1;
+    const unsigned char* sA = smem + PAR * STAGE;
     const unsigned char* sB = sA + A_BYTES;
     f32x4 af[2][TM], bf[2][TN];
     float bs[2][TN][4];
@@ -304,8 +315,21 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_kernel(const ConvA
   };
   advance();
   stage2(0, -1);
-  for (int t = 0; t + 1 < T; ++t) ktile(t, std::true_type{});
-  ktile(T - 1, std::false_type{});
+  {
+    using P0 = std::integral_constant<int, 0>;
+    using P1 = std::integral_constant<int, 1>;
+    int t = 0;
+    for (; t + 2 < T; t += 2) {
+      ktile(P0{}, std::true_type{});
+      ktile(P1{}, std::true_type{});
+    }
+    if (t + 2 == T) {
+      ktile(P0{}, std::true_type{});
+      ktile(P1{}, std::false_type{});
+    } else {
+      ktile(P0{}, std::false_type{});
+    }
+  }
 
   // epilogue: affine (folded BN or bias) -> leaky -> + addend -> store (x1 or x2-replicated), through
   // buffer descriptors based at the tile's first pixel and column (see the row tables above)
