@@ -182,7 +182,8 @@ struct WgradArgs {
   const float* dz;        // plane (B, Ho+2, Wo+2, z_cs)
   const float* a;         // input activation view
   float* slabs;           // [splits][Cout][taps*Cin]
-  const float* zero;      // >= 512 zero bytes (rows beyond M)
+  const float* zero;      // >= 512 zero bytes (unused since the pixel table; kept for the argument layout)
+  const uint2* tab;       // pixel table of this conv (vy_launch_wgrad_table): [M rounded up to 32, + 32] entries
   int B, Ho, Wo, M;       // M = B*Ho*Wo
   int z_cs, Cout;
   int a_Hp, a_Wp, a_cs, a_co, stride;
@@ -190,6 +191,11 @@ struct WgradArgs {
   int splits, k_per_split;  // k_per_split pixels (multiple of 32) per split
 };
 hipError_t vy_launch_wgrad(const WgradArgs& a, hipStream_t s);
+// per-pixel byte offsets (dz vector, input-plane centre pixel shifted by one row + one column) for vy_launch_wgrad;
+// n_entries = vy_wgrad_table_entries(M); both planes must be smaller than 4 GiB
+inline size_t vy_wgrad_table_entries(long long M) { return (size_t)((M + 31) / 32 * 32 + 32); }
+hipError_t vy_launch_wgrad_table(void* tab, int M, int n_entries, int Ho, int Wo, int z_cs, int a_Hp, int a_Wp, int a_cs,
+                                 int stride, hipStream_t s);
 // dst[i] = sum_s slabs[s][i]  (fixed order)
 hipError_t vy_launch_slab_reduce(const float* slabs, int splits, long long n, float* dst, hipStream_t s);
 

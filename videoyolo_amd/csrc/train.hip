@@ -43,6 +43,8 @@ struct VyTrain {
   std::vector<ZPlane> z;               // per conv
   std::vector<size_t> save_idx;        // per conv: float offset of [2][C] saved mean/invstd
   std::vector<int> splits, kps;        // per conv wgrad split-K
+  std::vector<size_t> tab_off;         // per conv: byte offset of its weight-gradient pixel table in the workspace
+  bool tabs_built = false;
   std::vector<SgdSeg> segs;
   std::vector<int32_t> chunk_seg;
   bool seg_uploaded = false;
@@ -238,6 +240,16 @@ size_t train_plan(vy_net* net, int b, int h, int w, bool commit) {
       chunk_seg.push_back(c);
     }
   }
+  // weight-gradient pixel tables (wgrad.hip): 8 bytes per output pixel of every conv but the stem
+  std::vector<size_t> tab_off(net->convs.size(), 0);
+  for (size_t i = 0; i < net->convs.size(); ++i) {
+    const ConvT& c = net->convs[i];
+    if (c.is_stem) continue;
+    const int div_in = net->planes[c.in_plane].div;
+    const long long M = (long long)b * (h / div_in / c.stride) * (w / div_in / c.stride);
+    tab_off[i] = off;
+    off += al256(vy_wgrad_table_entries(M) * 8);
+  }
   const size_t seg_off = off;
   off += al256(segs.size() * sizeof(SgdSeg));
   const size_t chunk_off = off;
@@ -265,6 +277,8 @@ size_t train_plan(vy_net* net, int b, int h, int w, bool commit) {
     t->save_idx = save;
     t->splits = splits;
     t->kps = kps;
+    t->tab_off = tab_off;
+    t->tabs_built = false;
     t->segs = segs;
     t->chunk_seg = chunk_seg;
     t->seg_uploaded = false;
@@ -500,6 +514,7 @@ int launch_wgrad(const TrainCtx& c, size_t ci, const float* dzp, int dz_cs, int 
   w.Cin = cv.cin;
   w.splits = c.t->splits[ci];
   w.k_per_split = c.t->kps[ci];
+  w.tab = reinterpret_cast<const uint2*>(net->dev_ws + c.t->tab_off[ci]);
   if (!g_labels_done) g_labels.note("wgrad", cv.name, w.M, w.Cout, (double)cv.k * cv.k * cv.cin);
   HIP_TRY(vy_launch_wgrad(w, ws));
   HIP_TRY(vy_launch_slab_reduce(c.slabs(), w.splits, (long long)cv.cout * cv.k * cv.k * cv.cin,
@@ -507,9 +522,32 @@ int launch_wgrad(const TrainCtx& c, size_t ci, const float* dzp, int dz_cs, int 
   return 0;
 }
 
+// the weight-gradient pixel tables depend on the planned shape only: built once after vy_net_bind_train
+int build_wgrad_tables(const TrainCtx& c) {
+  vy_net* net = c.net;
+  for (size_t ci = 0; ci < net->convs.size(); ++ci) {
+    const ConvT& cv = net->convs[ci];
+    if (cv.is_stem) continue;
+    const PlaneT& ip = net->planes[cv.in_plane];
+    const int Ho = ip.H / cv.stride, Wo = ip.W / cv.stride;
+    const long long M = (long long)net->B * Ho * Wo;
+    const int z_cs = cv.p_gamma >= 0 ? c.t->z[ci].C : net->planes[cv.out_plane].C;
+    const unsigned long long zbytes = (unsigned long long)net->B * (Ho + 2) * (Wo + 2) * z_cs * 4ull;
+    const unsigned long long abytes = (unsigned long long)net->B * (ip.H + 2) * (ip.W + 2) * ip.C * 4ull;
+    if (zbytes >= (1ull << 32) || abytes >= (1ull << 32))
+      return fail(VY_ERR_UNSUPPORTED, "training plane of '%s' is 4 GiB or larger (32-bit pixel offsets)", cv.name.c_str());
+    HIP_TRY(vy_launch_wgrad_table(net->dev_ws + c.t->tab_off[ci], (int)M, (int)vy_wgrad_table_entries(M), Ho, Wo, z_cs,
+                                  ip.H + 2, ip.W + 2, ip.C, cv.stride, c.s));
+  }
+  c.t->tabs_built = true;
+  return 0;
+}
+
 int backward_train(const TrainCtx& c, const float* x) {
   vy_net* net = c.net;
   const int B = net->B;
+  if (!c.t->tabs_built)
+    if (int rc = build_wgrad_tables(c)) return rc;
   // which channel ranges of each gradient plane already hold a contribution
   std::vector<std::vector<std::pair<int, int>>> touched(net->planes.size());
   auto covered = [&](int plane, int lo, int hi) -> int {  // 1 accumulate, 0 overwrite, -1 partial overlap

@@ -29,6 +29,41 @@ __device__ __forceinline__ void lds_dma16(const float* gptr, unsigned lds_addr) 
 #endif
 }
 
+// the same through a wave-uniform base (SGPR pair) + a per-lane 32-bit byte offset (see conv_igemm.hip)
+__device__ __forceinline__ void lds_dma16_s(unsigned voff, const float* sbase, unsigned lds_addr) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_addr)
+               : "memory", "m0");
+#endif
+}
+
+// Pixel table of one conv (built once per plan by wgrad_table_kernel): for output pixel p the byte offset of its dz
+// vector inside the dz plane and of its (stride-scaled) centre pixel inside the input plane, shifted by one row and
+// one column so that every tap offset is non-negative.  Entries M .. pad are "dead" pixels: a zero border pixel of
+// the dz plane (contributes 0 to every sum) and a valid input pixel.  With it the k-loop needs no coordinates at all:
+// the fp32 MFMA shares the vector pipe (tools/probe/coissue_probe.hip), and the incremental per-lane coordinates of
+// round 1 cost 92 vector instructions per 64 MFMAs.
+__global__ __launch_bounds__(256) void wgrad_table_kernel(uint2* __restrict__ tab, int M, int n_entries, int Ho, int Wo,
+                                                          int z_cs, int a_Hp, int a_Wp, int a_cs, int stride) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= n_entries) return;
+  const int pp = p < M ? p : 0;
+  const int x = pp % Wo, t = pp / Wo, y = t % Ho, b = t / Ho;
+  const unsigned long long zo = ((unsigned long long)(b * (Ho + 2) + y + 1) * (Wo + 2) + x + 1) * z_cs * 4ull;
+  const unsigned long long ao = ((unsigned long long)(b * a_Hp + y * stride + 1) * a_Wp + x * stride + 1) * a_cs * 4ull;
+  uint2 e;
+  e.x = p < M ? (unsigned)zo : 0u;  // dead pixel: plane pixel (0, 0) of image 0 — a zero border pixel
+  e.y = (unsigned)ao;
+  tab[p] = e;
+}
+
+hipError_t vy_launch_wgrad_table(void* tab, int M, int n_entries, int Ho, int Wo, int z_cs, int a_Hp, int a_Wp, int a_cs,
+                                 int stride, hipStream_t s) {
+  hipLaunchKernelGGL(wgrad_table_kernel, dim3((n_entries + 255) / 256), dim3(256), 0, s, static_cast<uint2*>(tab), M,
+                     n_entries, Ho, Wo, z_cs, a_Hp, a_Wp, a_cs, stride);
+  return hipGetLastError();
+}
+
 // KP = pixels per k-step (LDS stage): 32 -> 64 KiB double buffer, 2 blocks / CU.  (16 -> 32 KiB and 4 blocks / CU
 // was measured: faster alone, slower beside the dgrad chain it shares the chip with — 407 vs 414 frames/s.)
 // BM = output channels per block tile: 128, or 64 for the layers with Cout <= 64 (the 208x208 / 104x104 convs of
@@ -63,15 +98,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a, const 
   // this lane's fixed column chunk in both tiles
   const int a_chunk = lane % A_CPR, a_sub = lane / A_CPR;  // dz: chunk inside the row, pixel row inside the instruction
   const int ao = o0 + a_chunk * 4;        // dz channel of this chunk
-  const bool a_ok = ao < a.z_cs;          // (padded) channel exists in the dz plane
   const int chunk = lane & 31;            // activation tile: 16-B chunk inside a 512-B row
   const int bn = n0 + chunk * 4;          // n column of this chunk
-  const bool b_ok = bn < Ntot;
+  const bool b_ok = bn < Ntot;            // columns past k*k*Cin: tap 0 / channel 0 (the column is never stored)
   const int tap = b_ok ? bn / a.Cin : 0;
   const int cin = b_ok ? bn - tap * a.Cin : 0;
   const int pad = a.k >> 1;
   const int dy = a.k == 3 ? tap / 3 - pad : 0, dx = a.k == 3 ? tap % 3 - pad : 0;
-  const int Hzp = a.Ho + 2, Wzp = a.Wo + 2;
 
   f32x16 acc[2][TJ];
 #pragma unroll
@@ -81,90 +114,40 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a, const 
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-  // Each lane stages the same pixel rows of both tiles every k-step (activations: row 2*(j*4+wave) + h; dz:
-  // row A_RPI*(j*4+wave) + a_sub).  Their source pointers are carried incrementally: +KP pixels per k-step,
-  // plus constant skips over the zero border when the pixel index wraps to the next image row / the next
-  // image — no integer division and no 64-bit multiplies inside the k-loop.
-  int zy[NJA], zx[NJA], py[NJ], px[NJ];
-  const float* zp[NJA];
-  const float* ap[NJ];
+  // Staging.  Each lane stages the same pixel rows of both tiles every k-step (activations: row 2*(j*4+wave) + h;
+  // dz: row A_RPI*(j*4+wave) + a_sub).  Their byte offsets come from the conv's pixel table, one 8-byte entry per
+  // row and k-step, loaded a k-step ahead; the DMA address is a wave-uniform base + (table offset + the lane's
+  // constant: its channel chunk / its tap and input channel): one vector add per DMA instruction and nothing else.
+  // Rows past the end of the pixel range are dead table entries (a zero dz pixel: they add 0).  Lanes whose chunk lies
+  // past Cout / past k*k*Cin read whatever follows in memory: those rows / columns of the tile are never stored,
+  // and an MFMA output element depends on its own row and column only.
+  const uint2* tab = a.tab + p_begin;                                      // wave-uniform
+  const float* z_base = a.dz;
+  const float* a_base = a.a + a.a_co - (long long)(a.a_Wp + 1) * a.a_cs;  // tap offsets become >= 0
+  const unsigned zc = (unsigned)ao * 4u;
+  const unsigned ac = (unsigned)((((dy + 1) * a.a_Wp + (dx + 1)) * a.a_cs + cin) * 4);
+  const int zrow0 = A_RPI * wave + a_sub, arow0 = 2 * wave + h;  // + 4 * A_RPI * j / + 8 * j
+  unsigned tz[NJA], ta[NJ];
+  auto load_offsets = [&](int t) {
 #pragma unroll
-  for (int j = 0; j < NJA; ++j) {
-    const int p = p_begin + A_RPI * (j * 4 + wave) + a_sub;
-    zx[j] = p % a.Wo;
-    const int tt = p / a.Wo;
-    zy[j] = tt % a.Ho;
-    const int b = tt / a.Ho;
-    zp[j] = a.dz + ((long long)(b * Hzp + zy[j] + 1) * Wzp + zx[j] + 1) * a.z_cs + ao;
-  }
+    for (int j = 0; j < NJA; ++j) tz[j] = tab[t * KP + zrow0 + 4 * A_RPI * j].x;
 #pragma unroll
-  for (int j = 0; j < NJ; ++j) {
-    const int p = p_begin + 2 * (j * 4 + wave) + h;
-    px[j] = p % a.Wo;
-    const int tt = p / a.Wo;
-    py[j] = tt % a.Ho;
-    const int b = tt / a.Ho;
-    ap[j] = a.a + ((long long)(b * a.a_Hp + py[j] * a.stride + 1 + dy) * a.a_Wp + px[j] * a.stride + 1 + dx) * a.a_cs +
-            a.a_co + cin;
-  }
-  const long long z_step = (long long)KP * a.z_cs, a_step = (long long)KP * a.stride * a.a_cs;
-  const long long z_row = 2LL * a.z_cs, a_row = (long long)(a.a_Wp - a.Wo) * a.stride * a.a_cs;
-  const long long z_img = 2LL * Wzp * a.z_cs, a_img = (long long)(a.a_Hp - a.Ho * a.stride) * a.a_Wp * a.a_cs;
+    for (int j = 0; j < NJ; ++j) ta[j] = tab[t * KP + arow0 + 8 * j].y;
+  };
   const unsigned lds0 = (unsigned)(unsigned long long)LDS_PTR(smem);
-  // DMA of tile t into buffer buf: the activation instruction j of this wave, and (j < NJA) the dz instruction j
-  auto stage = [&](int t, int buf, int j) {
+  // DMA of tile t + 1 (whose offsets are in tz / ta) into buffer buf: the activation instruction j of this wave and
+  // (j < NJA) the dz instruction j
+  auto stage = [&](int buf, int j) {
     const int q = j * 4 + wave;
-    const bool live = p_begin + t * KP + 2 * q + h < p_end;
-    if constexpr (BM == 128) {
-      // both tiles stage the same pixel rows: one set of coordinates advances both pointers
-      lds_dma16(live && a_ok ? zp[j] : a.zero, lds0 + buf * STAGE + q * 1024);
-      lds_dma16(live && b_ok ? ap[j] : a.zero, lds0 + buf * STAGE + TILE_A + q * 1024);
-      px[j] += KP;
-      zp[j] += z_step;
-      ap[j] += a_step;
-      while (px[j] >= a.Wo) {
-        px[j] -= a.Wo;
-        zp[j] += z_row;
-        ap[j] += a_row;
-        if (++py[j] == a.Ho) {
-          py[j] = 0;
-          zp[j] += z_img;
-          ap[j] += a_img;
-        }
-      }
-    } else {
-      if (j < NJA) {  // dz: four pixel rows per instruction, its own coordinates
-        const int jz = j < NJA ? j : 0;
-        const bool zlive = p_begin + t * KP + A_RPI * q + a_sub < p_end;
-        lds_dma16(zlive && a_ok ? zp[jz] : a.zero, lds0 + buf * STAGE + q * 1024);
-        zx[jz] += KP;
-        zp[jz] += z_step;
-        while (zx[jz] >= a.Wo) {
-          zx[jz] -= a.Wo;
-          zp[jz] += z_row;
-          if (++zy[jz] == a.Ho) {
-            zy[jz] = 0;
-            zp[jz] += z_img;
-          }
-        }
-      }
-      lds_dma16(live && b_ok ? ap[j] : a.zero, lds0 + buf * STAGE + TILE_A + q * 1024);
-      px[j] += KP;
-      ap[j] += a_step;
-      while (px[j] >= a.Wo) {
-        px[j] -= a.Wo;
-        ap[j] += a_row;
-        if (++py[j] == a.Ho) {
-          py[j] = 0;
-          ap[j] += a_img;
-        }
-      }
-    }
+    if (j < NJA) lds_dma16_s(tz[j < NJA ? j : 0] + zc, z_base, lds0 + buf * STAGE + q * 1024);
+    lds_dma16_s(ta[j] + ac, a_base, lds0 + buf * STAGE + TILE_A + q * 1024);
   };
 
   if (T > 0) {
+    load_offsets(0);
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) stage(0, 0, j);
+    for (int j = 0; j < NJ; ++j) stage(0, j);
+    if (T > 1) load_offsets(1);
   }
   for (int t = 0; t < T; ++t) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of tile t has landed
@@ -199,9 +182,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a, const 
           for (int j = 0; j < TJ; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s4][i], bv[s4][j], acc[i][j], 0, 0, 0);
         // a quarter of the next tile's DMA, issued while this group's MFMAs occupy the matrix pipe
-        if (s4 == 0 && more) stage(t + 1, (t + 1) & 1, g);
+        if (s4 == 0 && more) stage((t + 1) & 1, g);
       }
     }
+    if (t + 2 < T) load_offsets(t + 2);  // consumed by the stage() calls of the next iteration, after its vmcnt(0)
   }
 
   float* slab = a.slabs + (long long)split * a.Cout * Ntot;
@@ -238,7 +222,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a, const 
 }
 
 hipError_t vy_launch_wgrad(const WgradArgs& a, hipStream_t s) {
-  if (a.Cin % 32 != 0 || a.k_per_split % 32 != 0 || a.splits < 1 || (a.z_cs & 3) || (a.a_cs & 3) || (a.a_co & 3))
+  if (a.Cin % 32 != 0 || a.k_per_split % 32 != 0 || a.splits < 1 || (a.z_cs & 3) || (a.a_cs & 3) || (a.a_co & 3) || !a.tab)
     return hipErrorInvalidValue;
   const int Ntot = a.k * a.k * a.Cin;
   const int tiles_n = (Ntot + 127) / 128;
