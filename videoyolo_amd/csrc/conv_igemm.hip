@@ -471,8 +471,9 @@ static hipError_t launch_cfg(const ConvArgs& a, hipStream_t s) {
 // batch 64): a launch of T tiles takes ceil(T / 256) x (alpha(tile) x K + O(tile)) — every CU works through its
 // share of the tiles at a rate that does not depend on how many blocks it holds (2 resident 128x128 blocks, 3 of
 // 128x64, 4 of 64x64), and what is lost is the last, partly filled round of the 256 CUs.  Fitted per tile, in
-// microseconds: alpha = 0.0634 / 0.0347 / 0.0177 per unit of K (128x64 costs 0.547 of 128x128, not 0.5: twice the
-// LDS-DMA bytes per FLOP), fixed part O = 6.7 / 1.8 / 1.0 (prologue tables + the epilogue of 64 / 32 / 16
+// microseconds (refitted after the k-loop lost its vector instructions): alpha = 0.0543 / 0.0273 / 0.0145 per unit
+// of K (the 128x64 tile now costs exactly half of 128x128: its old 0.547 was the vector-instruction overhead of twice
+// the DMA instructions per FLOP), fixed part O = 4.5 / 2.6 / 1.4 (prologue tables + the epilogue of 64 / 32 / 16
 // accumulator registers per lane): short-K 1x1 layers prefer the small tiles, long-K 3x3 layers the large one.
 // The smallest predicted time wins; a smaller tile has to be better by 0.5 %.  (A two-wave 64x32 tile was tried
 // for the 13x13 maps at batch 16, which are short of blocks: 461 vs 337 us on the K = 9216 data gradients.)
@@ -490,7 +491,7 @@ static void select_cfg(const ConvArgs& a, int* bm, int* bn) {
     int bm, bn;
     double alpha, fixed;
   };
-  const Cand cands[3] = {{128, 128, 0.0634, 6.7}, {128, 64, 0.0347, 1.8}, {64, 64, 0.0177, 1.0}};
+  const Cand cands[3] = {{128, 128, 0.0543, 4.5}, {128, 64, 0.0273, 2.6}, {64, 64, 0.0145, 1.4}};
   const double K = (double)a.ntaps * a.Kc;
   double best = 1e300;
   for (const Cand& c : cands) {
