@@ -23,8 +23,12 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // ---------------------------------------------------------------------------------------------
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-// rows per block: 2, or 1 for very wide frames (the strip must fit in LDS: 3 x (rows + 2) x (W + 8) floats)
-static int stem_rows(int W) { return 3 * 4 * (W + 8) * 4 <= 120 * 1024 ? 2 : 1; }
+// rows per block: 4 (the strip's two halo rows are then half of its payload: 1.5x input re-read instead of 2x), 2 or
+// 1 for wide frames (the strip must fit in LDS: 3 x (rows + 2) x (W + 8) floats)
+static int stem_rows(int W) {
+  if (3 * 6 * (W + 8) * 4 <= 64 * 1024) return 4;
+  return 3 * 4 * (W + 8) * 4 <= 120 * 1024 ? 2 : 1;
+}
 
 int vy_stem_blocks(int B, int H, int W) { return B * H / stem_rows(W); }
 
@@ -38,7 +42,7 @@ __global__ __launch_bounds__(256) void stem_kernel(const StemArgs a, double* __r
   const int lrow = lane & 31, h = lane >> 5;
   constexpr int kRsrcFlags = 0x00020000;
   const int Wp = a.W + 8, srows = rows + 2;
-  const int rpb = a.H / rows;                    // blocks per frame (H % 32 == 0, rows in {1, 2})
+  const int rpb = a.H / rows;                    // blocks per frame (H % 32 == 0, rows in {1, 2, 4})
   const int b = blockIdx.x / rpb, y0 = (blockIdx.x - b * rpb) * rows;
   // ---- stage the input strip: rows y0-1 .. y0+rows of the three channels
   {
