@@ -1,0 +1,61 @@
+"""-m "not gpu": host logic of bench.py that does not need a GPU — the parsing of the rocprofv3 --pmc counter
+files behind roofline.traffic (with a stand-in for rocprofv3 that writes the CSV a real run produces), and the
+kernel-name shortening."""
+import os
+import stat
+import sys
+import textwrap
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+_FAKE = textwrap.dedent('''\
+    #!/usr/bin/env python3
+    # stand-in for rocprofv3: rocprofv3 --pmc COUNTER --output-format csv -d DIR -- python bench.py ...
+    import os, sys
+    a = sys.argv[1:]
+    counter, d = a[a.index("--pmc") + 1], a[a.index("-d") + 1]
+    os.makedirs(os.path.join(d, "host"), exist_ok=True)
+    rows = ["Correlation_Id,Dispatch_Id,Agent_Id,Queue_Id,Process_Id,Thread_Id,Grid_Size,Kernel_Id,Kernel_Name,Workgroup_Size,LDS_Block_Size,Scratch_Size,VGPR_Count,Accum_VGPR_Count,SGPR_Count,Counter_Name,Counter_Value,Start_Timestamp,End_Timestamp"]
+    conv = '"void conv_igemm_kernel<128, 128, 2, 2, false>(ConvArgs, int)"'
+    vals = {"FETCH_SIZE": (1000.0, 3000.0), "WRITE_SIZE": (500.0, 700.0)}[counter]   # KiB per dispatch
+    for i, v in enumerate(vals):
+        rows.append("1,%d,0,1,1,1,256,7,%s,256,0,0,64,0,32,%s,%f,0,1" % (i + 1, conv, counter, v))
+    rows.append('1,9,0,1,1,1,256,8,"__amd_rocclr_fillBufferAligned",256,0,0,64,0,32,%s,999999,0,1' % counter)
+    rows.append('1,10,0,1,1,1,256,9,"bn_fold_kernel(float*, FoldDesc const*, float)",256,0,0,64,0,32,%s,%f,0,1' % (counter, 10.0))
+    open(os.path.join(d, "host", "1_counter_collection.csv"), "w").write("\\n".join(rows) + "\\n")
+    ''')
+
+
+def test_short_kernel_name():
+    import bench
+    assert bench._short_kernel_name("void conv_igemm_kernel<128, 128, 2, 2, false>(ConvArgs, int)") == \
+        "void conv_igemm_kernel<128, 128, 2, 2, false>"
+    assert bench._short_kernel_name("(anonymous namespace)::hist_kernel(DetArgs, void*, int, int)") == \
+        "(anonymous namespace)::hist_kernel"
+    assert bench._short_kernel_name("__amd_rocclr_copyBuffer") == "__amd_rocclr_copyBuffer"
+
+
+def test_traffic_from_counter_files(tmp_path, monkeypatch):
+    import bench
+    fake = tmp_path / "rocprofv3"
+    fake.write_text(_FAKE)
+    fake.chmod(fake.stat().st_mode | stat.S_IEXEC)
+    monkeypatch.setattr(bench, "ROCPROF", str(fake))
+    out, note = bench.measure_hbm_traffic(["--steps", "1"], steps_run=2)
+    assert note is None
+    k = out["void conv_igemm_kernel<128, 128, 2, 2, false>"]
+    assert k["launches"] == 2
+    assert k["fetch_bytes"] == 2 * (1000.0 + 3000.0) * 1024 / 2          # KiB -> bytes, x2 (gfx950), mean per launch
+    assert k["write_bytes"] == (500.0 + 700.0) * 1024 / 2
+    assert k["hbm_bytes"] == k["fetch_bytes"] + k["write_bytes"]
+    # per step: library kernels only (no runtime fill / copy kernels), dispatches / steps_run
+    want = (k["hbm_bytes"] * 2 + (2 * 10.0 + 10.0) * 1024) / 2
+    assert abs(out["_per_step"] - want) < 1e-6
+
+
+def test_traffic_reports_a_missing_profiler(monkeypatch):
+    import bench
+    monkeypatch.setattr(bench, "ROCPROF", "/nonexistent/rocprofv3")
+    out, note = bench.measure_hbm_traffic([], 1)
+    assert out is None and "not found" in note
