@@ -102,6 +102,13 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_kernel(const ConvA
   constexpr unsigned kInvalidRow = 0x80000000u;
 
   const int tid = threadIdx.x;
+#ifdef VY_CONV_TRACE  // tools/probe/conv_tile_trace.hip: thread 0 stamps the tile's phases (never compiled into the library)
+#define VY_TRACE(slot) \
+  if (a.trace && tid == 0) a.trace[(long long)blockIdx.x * 8 + (slot)] = __builtin_amdgcn_s_memrealtime();
+#else
+#define VY_TRACE(slot)
+#endif
+  VY_TRACE(0)
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
@@ -315,6 +322,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_kernel(const ConvA
   };
   advance();
   stage2(0, -1);
+  VY_TRACE(1)
   {
     using P0 = std::integral_constant<int, 0>;
     using P1 = std::integral_constant<int, 1>;
@@ -331,6 +339,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_kernel(const ConvA
     }
   }
 
+  VY_TRACE(2)
   // epilogue: affine (folded BN or bias) -> leaky -> + addend -> store (x1 or x2-replicated), through
   // buffer descriptors based at the tile's first pixel and column (see the row tables above)
   constexpr int kRsrcFlags = 0x00020000;  // raw dword buffer, gfx9 data format 32
@@ -408,6 +417,13 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_kernel(const ConvA
     }
   }
 
+  VY_TRACE(3)
+#ifdef VY_CONV_TRACE
+  if (a.trace && tid == 0) {
+    a.trace[(long long)blockIdx.x * 8 + 4] = __builtin_amdgcn_s_getreg(4 | (31 << 11));   // HW_ID
+    a.trace[(long long)blockIdx.x * 8 + 5] = __builtin_amdgcn_s_getreg(20 | (31 << 11));  // XCC_ID
+  }
+#endif
   // train-mode BatchNorm: per-tile column sums of the raw accumulators (deterministic: fixed
   // order inside the tile, tiles are combined in order by the finalize kernel)
   if (a.stats) {

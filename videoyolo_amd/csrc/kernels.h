@@ -34,6 +34,9 @@ struct ConvArgs {
   int leaky;            // LeakyReLU(0.1) after the affine
   int dgrad;            // 0: W is the [n][k] operand (forward); 1: W is the [k][n] operand (dgrad)
   unsigned pk_dy, pk_dx;        // filled by the launcher: tap tables packed 2 bits / tap (value + 1)
+#ifdef VY_CONV_TRACE
+  unsigned long long* trace;    // tools/probe/conv_tile_trace.hip only: [block][8] phase timestamps (100 MHz) + CU id
+#endif
   unsigned long long pk_w;      // 4 bits / tap
 };
 
