@@ -97,8 +97,9 @@ int vy_net_param_set(vy_net* net, int32_t i, const float* host_src, void* stream
 int vy_net_param_get(vy_net* net, int32_t i, float* host_dst, void* stream);
 
 /* Shape planning.  Workspace bytes needed for inference on (batch, 3, height, width) input;
- * height and width must be multiples of 32 (stride-32 head), at most 4096 (alloc_size =
- * (128,128), yolo3.py:67-74). */
+ * height and width in [32, 4096] (alloc_size = (128,128), yolo3.py:67-74).  They need not be multiples of 32:
+ * like the reference, every stride-2 conv yields ceil(n / 2) rows and the x2 upsample is cropped to the route it is
+ * concatenated with (slice_like, yolo3.py:1177), so the heads have ceil(h / 32), ceil(h / 16), ceil(h / 8) rows. */
 size_t vy_net_workspace_bytes(const vy_net* net, int32_t batch, int32_t height, int32_t width);
 /* Bind a caller-owned device workspace of at least that size and plan for that shape.  Zeroes the
  * workspace (asynchronously, on `stream`): the padded activation planes rely on zero borders. */
@@ -191,6 +192,8 @@ int vy_prefetch_targets(const float* gt_boxes, const float* gt_ids, const float*
  * same element offsets as the parameter buffer: one contiguous range for the RCCL all-reduce) and a
  * training workspace (activations, raw conv outputs / their gradients, gradient planes, scratch).
  * ---------------------------------------------------------------------------------------------- */
+/* Training shapes: height and width multiples of 32, as train_yolov3.py produces them (0 / VY_ERR_UNSUPPORTED
+ * otherwise). */
 size_t vy_net_train_workspace_bytes(const vy_net* net, int32_t batch, int32_t height, int32_t width);
 /* Binds the training workspace (also serves inference at that shape), the gradient buffer and the
  * momentum buffer (the caller zero-initialises the momentum once); zeroes the workspace

@@ -226,6 +226,41 @@ def test_non_square_input(voc_classes, synth20):
         assert np.array_equal(net.read_head(i).cpu().numpy(), _oracle(synth20).raw_heads(x)[i])
 
 
+@pytest.mark.parametrize("shape", [(2, 3, 100, 136), (1, 3, 75, 93), (1, 3, 333, 250), (3, 3, 33, 47)])
+def test_sizes_that_are_not_multiples_of_32(voc_classes, synth20, shape):
+    """The reference takes any input size: stride-2 convs give ceil(n / 2) rows and the x2 upsample is cropped to
+    the route (slice_like, yolo3.py:1177).  Heads bit-exact, detections and kept rows like the CPU checker."""
+    rng = np.random.default_rng(shape[2])
+    x = rng.standard_normal(shape).astype(np.float32)
+    net = _net(voc_classes, synth20)
+    ids, scores, bboxes, keep = [t.cpu().numpy() for t in net(x, return_index=True)]
+    orc = _oracle(synth20)
+    ref = orc.raw_heads(x)
+    for i in range(3):
+        got = net.read_head(i).cpu().numpy()
+        assert got.shape == ref[i].shape == (shape[0], 75, -(-shape[2] // [32, 16, 8][i]), -(-shape[3] // [32, 16, 8][i]))
+        assert np.array_equal(got, ref[i]), "head %d: max |diff| %g" % (i, np.abs(got - ref[i]).max())
+    r = orc(x)
+    assert np.array_equal(keep, r[3]) and np.array_equal(ids, r[0])
+    np.testing.assert_allclose(scores, r[1], rtol=0, atol=TOL)
+    fin = np.isfinite(r[2])
+    np.testing.assert_allclose(bboxes[fin], r[2][fin], rtol=0, atol=TOL)
+    # the borders of every plane are still zero: a second, multiple-of-32 shape on the same handle stays exact
+    x2 = frames(1, 64)
+    net(x2)
+    for i in range(3):
+        assert np.array_equal(net.read_head(i).cpu().numpy(), orc.raw_heads(x2)[i])
+
+
+def test_training_keeps_multiples_of_32(voc_classes, synth20):
+    from videoyolo_amd import autograd, _lib
+    net = _net(voc_classes, synth20)
+    x = np.zeros((1, 3, 100, 136), np.float32)
+    with autograd.train_mode():
+        with pytest.raises(_lib.VyError, match="multiples of 32"):
+            net(x)
+
+
 def test_two_stream_batch_split_is_identical(voc_classes, synth20):
     """Large batches run as two half-batches on two HIP streams (twin handle sharing the parameters):
     same results as the single-stream path, also after the parameters or NMS settings change."""

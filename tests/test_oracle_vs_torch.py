@@ -57,7 +57,8 @@ class TorchYolo3:
                 break
             x = self.cell(x, "transitions.%d" % i, 1, 1)
             x = F.interpolate(x, scale_factor=2, mode="nearest")
-            x = torch.cat([x, routes[1 - i]], 1)
+            r = routes[1 - i]
+            x = torch.cat([x[:, :, :r.shape[2], :r.shape[3]], r], 1)  # slice_like, yolo3.py:1177
         return outs
 
     def decode(self, pred, i):
@@ -125,6 +126,28 @@ def test_heads_agree_with_torch(both):
     for a, b in zip(oh, th):
         assert a.shape == tuple(b.shape)
         np.testing.assert_allclose(a, b.numpy(), rtol=0, atol=1e-4)
+
+
+@pytest.mark.parametrize("hw", [(100, 136), (75, 93)])
+def test_sizes_that_are_not_multiples_of_32(synth20, hw):
+    """The reference crops the x2 upsample to the route it is concatenated with (slice_like, yolo3.py:1177) and a
+    stride-2 3x3 pad-1 conv maps n rows to ceil(n / 2): heads of ceil(H / 32), ceil(H / 16), ceil(H / 8) rows.
+    (100, 136) crops both upsamples on both axes; (75, 93) is odd at every level."""
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((1, 3) + hw).astype(np.float32)
+    orc, tm = O.OracleYolo3(20, synth20), TorchYolo3(20, synth20)
+    with torch.no_grad():
+        th = tm.forward_heads(x)
+    oh = orc.raw_heads(x)
+    for i, (a, b) in enumerate(zip(oh, th)):
+        d = [32, 16, 8][i]
+        assert a.shape == (1, 75, -(-hw[0] // d), -(-hw[1] // d)) == tuple(b.shape)
+        np.testing.assert_allclose(a, b.numpy(), rtol=1e-4, atol=1e-4)
+    od = orc.detections(x)
+    td = torch.cat([tm.decode(h, i) for i, h in enumerate(th)], 1).numpy()
+    assert od.shape == td.shape
+    np.testing.assert_allclose(od[..., 1], td[..., 1], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(od[..., 2:], td[..., 2:], rtol=1e-4, atol=1e-3)
 
 
 def test_decode_layout_agrees_with_torch(both):

@@ -145,7 +145,11 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_kernel(const ConvA
     const int b = t / a.LH;
     in_off[rr] = ((long long)(b * a.a_Hp + y * a.a_s + a.a_oy) * a.a_Wp + x * a.a_s + a.a_ox) * a.a_cs + a.a_co;
     const unsigned rel = (unsigned)(((long long)(b * a.o_Hp + y * a.o_s + a.o_oy) * a.o_Wp + x * a.o_s + a.o_ox) - pix0);
-    o_off[rr] = (m < a.M) ? rel * (unsigned)a.o_cs * 4u : kInvalidRow;
+    unsigned oo_row = (m < a.M) ? rel * (unsigned)a.o_cs * 4u : kInvalidRow;
+    // x2-replicated store (nearest upsample fused, layers.py:11-20) cropped to the route's size (slice_like,
+    // yolo3.py:1177): bit 0 / bit 1 of the (4-byte aligned) offset drop the row's second column / second row
+    if (a.ups == 2 && m < a.M) oo_row |= (2 * x + 1 >= a.o_Wp - 2 ? 1u : 0u) | (2 * y + 1 >= a.o_Hp - 2 ? 2u : 0u);
+    o_off[rr] = oo_row;
     r_off[rr] = (m < a.M) ? rel * (unsigned)a.r_cs * 4u : kInvalidRow;
   }
   __syncthreads();
@@ -384,11 +388,15 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_kernel(const ConvA
             vv = vv + sh;
           if (leaky) vv = vy_leaky(vv);
           if (has_res) vv = vv + rv[r];
-          buf_store_f32(vv, out_rsrc, oo[r], 0);
-          if (ups2) {
-            buf_store_f32(vv, out_rsrc, oo[r], ups_dx);
-            buf_store_f32(vv, out_rsrc, oo[r], ups_dy);
-            buf_store_f32(vv, out_rsrc, oo[r], ups_dy + ups_dx);
+          if (!ups2) {
+            buf_store_f32(vv, out_rsrc, oo[r], 0);
+          } else {  // an offset with bit 31 set is out of the descriptor's range: that store is dropped
+            const unsigned base = oo[r] & ~3u;
+            const unsigned no_dx = (oo[r] & 1u) << 31, no_dy = (oo[r] & 2u) << 30;
+            buf_store_f32(vv, out_rsrc, base, 0);
+            buf_store_f32(vv, out_rsrc, base | no_dx, ups_dx);
+            buf_store_f32(vv, out_rsrc, base | no_dy, ups_dy);
+            buf_store_f32(vv, out_rsrc, base | no_dx | no_dy, ups_dy + ups_dx);
           }
         }
       }

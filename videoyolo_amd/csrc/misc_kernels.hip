@@ -26,11 +26,12 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // rows per block: 4 (the strip's two halo rows are then half of its payload: 1.5x input re-read instead of 2x), 2 or
 // 1 for wide frames (the strip must fit in LDS: 3 x (rows + 2) x (W + 8) floats)
 static int stem_rows(int W) {
-  if (3 * 6 * (W + 8) * 4 <= 64 * 1024) return 4;
-  return 3 * 4 * (W + 8) * 4 <= 120 * 1024 ? 2 : 1;
+  const int Wp = ((W + 31) & ~31) + 8;
+  if (3 * 6 * Wp * 4 <= 64 * 1024) return 4;
+  return 3 * 4 * Wp * 4 <= 120 * 1024 ? 2 : 1;
 }
 
-int vy_stem_blocks(int B, int H, int W) { return B * H / stem_rows(W); }
+int vy_stem_blocks(int B, int H, int W) { return B * ((H + stem_rows(W) - 1) / stem_rows(W)); }
 
 template <bool RAW>
 __global__ __launch_bounds__(256) void stem_kernel(const StemArgs a, double* __restrict__ partials, const int rows) {
@@ -41,11 +42,14 @@ __global__ __launch_bounds__(256) void stem_kernel(const StemArgs a, double* __r
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: descriptors stay scalar
   const int lrow = lane & 31, h = lane >> 5;
   constexpr int kRsrcFlags = 0x00020000;
-  const int Wp = a.W + 8, srows = rows + 2;
-  const int rpb = a.H / rows;                    // blocks per frame (H % 32 == 0, rows in {1, 2, 4})
+  // strip row pitch: the frame's width rounded up to whole 32-pixel tiles (+ 4 floats of margin either side); any
+  // H and W are accepted — rows past H are skipped, pixels past W are computed on whatever the strip holds there
+  // and dropped by the store descriptor's range
+  const int Wp = ((a.W + 31) & ~31) + 8, srows = rows + 2;
+  const int rpb = (a.H + rows - 1) / rows;       // blocks per frame
   const int b = blockIdx.x / rpb, y0 = (blockIdx.x - b * rpb) * rows;
   // ---- stage the input strip: rows y0-1 .. y0+rows of the three channels
-  {
+  if ((a.W & 3) == 0) {
     const int w4 = a.W >> 2;
     const int total = 3 * srows * w4;
     for (int i = threadIdx.x; i < total; i += 256) {
@@ -55,6 +59,15 @@ __global__ __launch_bounds__(256) void stem_kernel(const StemArgs a, double* __r
       if (y >= 0 && y < a.H) v = *reinterpret_cast<const f32x4*>(a.x + (((long long)b * 3 + c) * a.H + y) * a.W + q * 4);
       *reinterpret_cast<f32x4*>(strip + (c * srows + rr) * Wp + 4 + q * 4) = v;
     }
+  } else {  // rows of a width that is not a multiple of 4 are not 16-byte aligned: element loads
+    const int total = 3 * srows * a.W;
+    for (int i = threadIdx.x; i < total; i += 256) {
+      const int q = i % a.W, rr = (i / a.W) % srows, c = i / (a.W * srows);
+      const int y = y0 - 1 + rr;
+      strip[(c * srows + rr) * Wp + 4 + q] = (y >= 0 && y < a.H) ? a.x[(((long long)b * 3 + c) * a.H + y) * a.W + q] : 0.0f;
+    }
+  }
+  {
     for (int i = threadIdx.x; i < 3 * srows * 2; i += 256) {  // the zero columns left and right of every row
       const int side = i & 1, rr = i >> 1;
       strip[rr * Wp + (side ? a.W + 4 : 3)] = 0.0f;
@@ -80,12 +93,13 @@ __global__ __launch_bounds__(256) void stem_kernel(const StemArgs a, double* __r
   }
   __syncthreads();
   double s1 = 0.0, s2 = 0.0;
-  const int tiles_per_row = a.W / 32;
+  const int tiles_per_row = (a.W + 31) / 32;
   const int tiles = rows * tiles_per_row;
   const unsigned st_off = (unsigned)(lrow * 4 + h * 4 * 128);  // this lane's channel, pixel rows 4h.. of the tile
   for (int tile = wave; tile < tiles; tile += 4) {  // wave-uniform
     const int ry = tile / tiles_per_row, x0 = (tile - ry * tiles_per_row) * 32;
     const int y = y0 + ry;
+    if (y >= a.H) continue;  // wave-uniform
     const float* centre = strip + (ry + 1) * Wp + 4 + x0 + lrow;
     float av[14];
 #pragma unroll
@@ -97,7 +111,8 @@ __global__ __launch_bounds__(256) void stem_kernel(const StemArgs a, double* __r
     for (int s = 0; s < 14; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bw[s], acc, 0, 0, 0);
     // the tile's 32 output pixels are 4 KiB of contiguous memory (32 channels x 4 B per pixel)
     const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        a.out + ((long long)(b * (a.H + 2) + y + 1) * (a.W + 2) + x0 + 1) * 32, 0, 32 * 128, kRsrcFlags);
+        a.out + ((long long)(b * (a.H + 2) + y + 1) * (a.W + 2) + x0 + 1) * 32, 0,
+        (a.W - x0 < 32 ? a.W - x0 : 32) * 128, kRsrcFlags);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       float v = acc[r];
@@ -131,14 +146,14 @@ __global__ __launch_bounds__(256) void stem_kernel(const StemArgs a, double* __r
 
 static hipError_t stem_check(const StemArgs& a) {
   // the stem writes a 32-channel plane of its own (activation plane or, in training, the z plane)
-  if (a.Cout != 32 || a.out_cs != 32 || a.out_co != 0 || a.W % 32 != 0) return hipErrorInvalidValue;
+  if (a.Cout != 32 || a.out_cs != 32 || a.out_co != 0 || a.W < 1 || a.H < 1) return hipErrorInvalidValue;
   return hipSuccess;
 }
 
 hipError_t vy_launch_stem(const StemArgs& a, hipStream_t s) {
   if (stem_check(a) != hipSuccess) return hipErrorInvalidValue;
   const int rows = stem_rows(a.W);
-  const size_t lds = (size_t)3 * (rows + 2) * (a.W + 8) * sizeof(float);
+  const size_t lds = (size_t)3 * (rows + 2) * (((a.W + 31) & ~31) + 8) * sizeof(float);
   if (lds > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_kernel<false>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -152,7 +167,7 @@ hipError_t vy_launch_stem(const StemArgs& a, hipStream_t s) {
 hipError_t vy_launch_stem_raw(const StemArgs& a, double* partials, hipStream_t s) {
   if (stem_check(a) != hipSuccess) return hipErrorInvalidValue;
   const int rows = stem_rows(a.W);
-  const size_t lds = (size_t)3 * (rows + 2) * (a.W + 8) * sizeof(float);
+  const size_t lds = (size_t)3 * (rows + 2) * (((a.W + 31) & ~31) + 8) * sizeof(float);
   if (lds > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_kernel<true>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -122,8 +122,8 @@ int vy_net_param_get(vy_net* net, int32_t i, float* host_dst, void* stream) {
 
 static int check_shape(int32_t batch, int32_t h, int32_t w) {
   if (batch < 1) return fail(VY_ERR_INVALID, "batch %d < 1", batch);
-  if (h < 32 || w < 32 || h % 32 || w % 32 || h > 4096 || w > 4096)
-    return fail(VY_ERR_INVALID, "input %dx%d: height and width must be multiples of 32 in [32, 4096]", h, w);
+  if (h < 32 || w < 32 || h > 4096 || w > 4096)
+    return fail(VY_ERR_INVALID, "input %dx%d: height and width must lie in [32, 4096]", h, w);
   return 0;
 }
 

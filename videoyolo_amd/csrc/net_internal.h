@@ -247,12 +247,16 @@ struct vy_net {
     off += al(sizeof(FoldDesc) * folds.size());
     const size_t det_off = off;
     int n_items = 0;
-    for (int i = 0; i < 3; ++i) n_items += 3 * (h / planes[head_plane[i]].div) * (w / planes[head_plane[i]].div);
+    // a plane's spatial size = ceil(input / div): every stride-2 3x3 pad-1 conv maps n rows to ceil(n / 2), and the
+    // x2 upsample is cropped to the route it is concatenated with (slice_like, yolo3.py:1177) — inputs need not be
+    // multiples of 32
+    auto cdiv = [](int a, int d) { return (a + d - 1) / d; };
+    for (int i = 0; i < 3; ++i) n_items += 3 * cdiv(h, planes[head_plane[i]].div) * cdiv(w, planes[head_plane[i]].div);
     off += al(vy_det_scratch_bytes(b, n_items, num_class));
     const size_t pl_off = off;
     size_t fl = 0;
     for (auto& p : planes) {
-      const int ph = h / p.div, pw = w / p.div;
+      const int ph = cdiv(h, p.div), pw = cdiv(w, p.div);
       if (commit) {
         p.H = ph;
         p.W = pw;
@@ -299,7 +303,7 @@ struct vy_net {
     a.res = c.res_plane >= 0 ? plane_ptr(c.res_plane) : nullptr;
     a.out = plane_ptr(c.out_plane);
     a.stats = nullptr;
-    const int Ho = ip.H / c.stride, Wo = ip.W / c.stride;
+    const int Ho = (ip.H + c.stride - 1) / c.stride, Wo = (ip.W + c.stride - 1) / c.stride;
     a.B = B;
     a.LH = Ho;
     a.LW = Wo;
@@ -321,8 +325,8 @@ struct vy_net {
     a.w_cin = c.cin;
     a.w_cout = c.cout;
     a.N = c.cout;
-    a.o_Hp = Ho * c.ups + 2;
-    a.o_Wp = Wo * c.ups + 2;
+    a.o_Hp = op.H + 2;  // ups == 2: the route's size, which may be one short of 2 x (Ho, Wo) — the store crops
+    a.o_Wp = op.W + 2;
     a.o_cs = op.C;
     a.o_co = c.out_co;
     a.o_s = c.ups;

@@ -735,8 +735,17 @@ int backward_train(const TrainCtx& c, const float* x) {
 
 extern "C" {
 
+// Training keeps the reference scripts' shapes: multiples of 32 (train_yolov3.py resizes to --data-shape, gluoncv's
+// random shapes step by 32).  Inference takes any size (cropped upsample).
+static int check_train_shape(int32_t height, int32_t width) {
+  if (height % 32 || width % 32)
+    return fail(VY_ERR_UNSUPPORTED, "training input %dx%d: height and width must be multiples of 32", height, width);
+  return 0;
+}
+
 size_t vy_net_train_workspace_bytes(const vy_net* net, int32_t batch, int32_t height, int32_t width) {
   if (!net) return 0;
+  if (check_train_shape(height, width)) return 0;
   if (vy_net_workspace_bytes(net, batch, height, width) == 0) return 0;
   return train_plan(const_cast<vy_net*>(net), batch, height, width, false);
 }
@@ -744,6 +753,7 @@ size_t vy_net_train_workspace_bytes(const vy_net* net, int32_t batch, int32_t he
 int vy_net_bind_train(vy_net* net, void* dev_ws, size_t bytes, int32_t batch, int32_t height, int32_t width,
                       void* dev_grads, void* dev_momentum, void* stream) {
   if (!net || !dev_ws || !dev_grads || !dev_momentum) return fail(VY_ERR_INVALID, "null argument");
+  if (int rc = check_train_shape(height, width)) return rc;
   if (vy_net_workspace_bytes(net, batch, height, width) == 0) return VY_ERR_INVALID;
   const size_t need = train_plan(net, batch, height, width, false);
   if (bytes < need) return fail(VY_ERR_INVALID, "training workspace too small: %zu < %zu bytes", bytes, need);

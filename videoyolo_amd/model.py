@@ -717,7 +717,7 @@ class YOLOV3(object):
         torch = _torch()
         b, h, w = self._plan[:3]
         div = (32, 16, 8)[i]
-        out = torch.empty((b, 3 * (5 + len(self._classes)), h // div, w // div), dtype=torch.float32,
+        out = torch.empty((b, 3 * (5 + len(self._classes)), -(-h // div), -(-w // div)), dtype=torch.float32,
                           device=self._device)
         with torch.cuda.device(self._device):
             _lib.check(self._lib.vy_net_read_head(self._h, i, ctypes.c_void_p(out.data_ptr()), self._stream()))
