@@ -74,8 +74,14 @@ def test_planning_and_argument_errors():
     # conv-output activations: 38.6 M floats / frame at 416 + borders + scratch
     assert 38.6e6 * 4 < b1 < 1.25 * 38.6e6 * 4 + 4e6
     assert b1 < b2 < 2 * b1 + 1e6 and b608 > 2 * b1
-    assert lib.vy_net_workspace_bytes(h, 1, 400, 416) == 0      # not a multiple of 32
+    # inference plans any size in [32, 4096] (ceil-sized feature maps, cropped upsample); training multiples of 32
+    b400 = lib.vy_net_workspace_bytes(h, 1, 400, 416)
+    assert lib.vy_net_workspace_bytes(h, 1, 384, 416) < b400 < b1
+    assert lib.vy_net_workspace_bytes(h, 1, 16, 416) == 0 and lib.vy_net_workspace_bytes(h, 1, 416, 4100) == 0
+    assert "[32, 4096]" in lib.vy_last_error().decode()
+    assert lib.vy_net_train_workspace_bytes(h, 1, 400, 416) == 0
     assert "multiples of 32" in lib.vy_last_error().decode()
+    assert lib.vy_net_train_workspace_bytes(h, 1, 416, 416) > b1
     assert lib.vy_net_workspace_bytes(h, 0, 416, 416) == 0
     rc = lib.vy_net_bind_workspace(h, None, 0, 1, 416, 416, None)
     assert rc == -1
