@@ -281,6 +281,24 @@ def main():
         net.hybridize(False)
         result["latency_batch1"] = dict(lat, size=args.size, note="one frame resident in HBM -> 100 detection rows")
 
+    if rank == 0 and world == 1 and not args.no_latency and args.size == 608:
+        # BASELINE.json's metric names both frame sizes: the same batch at 416x416, timed the same way
+        x4 = torch.randn((args.batch, 3, 416, 416), generator=g, dtype=torch.float32).to(dev)
+        for _ in range(args.warmup):
+            net(x4)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            net(x4)
+        torch.cuda.synchronize()
+        dt4 = time.perf_counter() - t0
+        fps4 = args.batch * args.steps / dt4
+        gflop4 = 65.43 if args.classes == 20 else None  # forward GFLOP per 416x416 frame, 20 classes
+        result["also_416"] = {"frames_per_s": fps4, "ms_per_step": 1e3 * dt4 / args.steps, "batch": args.batch,
+                              "whole_step_tflops": None if gflop4 is None else fps4 * gflop4 / 1e3,
+                              "frac_of_fp32_mfma_peak": None if gflop4 is None else fps4 * gflop4 / 1e3 / FP32_MFMA_PEAK_TFLOPS}
+        del x4
+
     if rank == 0 and world == 1 and args.cpu_frames > 0:
         # CPU baseline: the oracle (a port of the same algorithm; NOT the reference's MXNet path,
         # which cannot be installed here) on a bounded sample of the same workload
