@@ -76,7 +76,18 @@ __device__ __forceinline__ void buf_store_f32(float v, __amdgpu_buffer_rsrc_t rs
 }
 #endif
 
-template <int BM, int BN, int WM, int WN, bool DGRAD>
+// workgroup barrier that waits for this wave's LDS traffic only (not for outstanding global loads: the deep
+// pipeline below keeps LDS-DMA of later k-steps in flight across it)
+__device__ __forceinline__ void lds_barrier() {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
+}
+
+template <int BM, int BN, int WM, int WN, bool DGRAD, int NS = 2>
+// NS = LDS stages.  2: the throughput configuration (2-4 resident blocks per CU hide each other's DMA latency).
+// 4: for launches of so few blocks that a CU holds one (batch 1, the 13x13 maps at batch 16): the k-step of a lone
+// 64x64 block is 0.43 us of matrix work but a DMA takes ~0.8 us to land, so three k-steps are kept in flight.
 // 2nd launch-bounds argument = waves per SIMD the register allocation must allow: two (2 blocks/CU of 4
 // waves, or one 8-wave block).  Without it hipcc let the register count drift past 256 and silently
 // halved the occupancy of some variants.
@@ -89,9 +100,9 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_kernel(const ConvA
   static_assert(NW == 4 || NW == 8, "4 or 8 waves");
   static_assert(A_INSTR >= 1 && B_INSTR >= 1, "tile too small for the wave count");
   static_assert(TM >= 1 && TN >= 1, "tile");
-  // one LDS object: [stage0 A|W][stage1 A|W][row tables]
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE + 2 * BM * 8];
-  long long* in_off = reinterpret_cast<long long*>(smem + 2 * STAGE);
+  // one LDS object: [stage0 A|W][stage1 A|W]...[row tables]
+  __shared__ __attribute__((aligned(16))) unsigned char smem[NS * STAGE + 2 * BM * 8];
+  long long* in_off = reinterpret_cast<long long*>(smem + NS * STAGE);
   // epilogue row tables: byte offset of the row's output pixel (and of its addend pixel) relative to the
   // tile's first pixel; kInvalidRow for rows past M.  The epilogue addresses memory through buffer
   // descriptors based at the tile's first pixel: 32-bit offsets (one v_add per element instead of
@@ -270,13 +281,17 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_kernel(const ConvA
   };
   // `parity` (which half of the double buffer holds this tile) is a compile-time constant: the k-loop is unrolled by
   // two, so the buffer offset folds into the ds_read immediates instead of one vector add per fragment read
-  auto ktile = [&](auto parity, auto prefetch) {
+  // (NS = 4: `parity` is the stage 0..3 holding this k-step, the prefetch goes three k-steps ahead into the stage the
+  // previous k-step just released, and `waitn` = DMA instructions that may stay in flight — loads return in order)
+  auto ktile = [&](auto parity, auto prefetch, auto waitn) {
     constexpr bool PREFETCH = decltype(prefetch)::value;
     constexpr int PAR = decltype(parity)::value;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    constexpr int WAITN = decltype(waitn)::value;
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAITN) : "memory");
+    if (NS == 2) __syncthreads();
+    else lds_barrier();
     if (PREFETCH) advance();
-    constexpr int nbuf = PAR ^ 1;
+    constexpr int nbuf = (PAR + NS - 1) % NS;
     const unsigned char* sA = smem + PAR * STAGE;
     const unsigned char* sB = sA + A_BYTES;
     f32x4 af[2][TM], bf[2][TN];
@@ -324,22 +339,57 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_kernel(const ConvA
       mfma_step(cur, 3);
     }
   };
-  advance();
-  stage2(0, -1);
-  VY_TRACE(1)
-  {
+  using W0 = std::integral_constant<int, 0>;
+  if constexpr (NS == 2) {
+    advance();
+    stage2(0, -1);
+    VY_TRACE(1)
     using P0 = std::integral_constant<int, 0>;
     using P1 = std::integral_constant<int, 1>;
     int t = 0;
     for (; t + 2 < T; t += 2) {
-      ktile(P0{}, std::true_type{});
-      ktile(P1{}, std::true_type{});
+      ktile(P0{}, std::true_type{}, W0{});
+      ktile(P1{}, std::true_type{}, W0{});
     }
     if (t + 2 == T) {
-      ktile(P0{}, std::true_type{});
-      ktile(P1{}, std::false_type{});
+      ktile(P0{}, std::true_type{}, W0{});
+      ktile(P1{}, std::false_type{}, W0{});
     } else {
-      ktile(P0{}, std::false_type{});
+      ktile(P0{}, std::false_type{}, W0{});
+    }
+  } else {
+    static_assert(NS == 2 || NS == 4, "2 or 4 stages");
+    using W1 = std::integral_constant<int, DMA_TOTAL>;       // one later k-step may still be in flight
+    using W2 = std::integral_constant<int, 2 * DMA_TOTAL>;   // two
+    for (int g = 0; g < NS - 1 && g < T; ++g) {  // k-steps 0..2 go out before any matrix work
+      advance();
+      stage2(g, -1);
+    }
+    VY_TRACE(1)
+    // k-step t: stage t % 4; prefetches k-step t + 3 if there is one; k-steps t+1 and t+2 (if any) stay in flight
+    auto kstep = [&](auto stage, int t) {
+      const int after = T - 1 - t;
+      if (after >= 3) ktile(stage, std::true_type{}, W2{});
+      else if (after == 2) ktile(stage, std::false_type{}, W2{});
+      else if (after == 1) ktile(stage, std::false_type{}, W1{});
+      else ktile(stage, std::false_type{}, W0{});
+    };
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+    using S2 = std::integral_constant<int, 2>;
+    using S3 = std::integral_constant<int, 3>;
+    int t = 0;
+    for (; t + 7 <= T; t += 4) {  // all four have a k-step to prefetch (t + 3 + 3 < T)
+      ktile(S0{}, std::true_type{}, W2{});
+      ktile(S1{}, std::true_type{}, W2{});
+      ktile(S2{}, std::true_type{}, W2{});
+      ktile(S3{}, std::true_type{}, W2{});
+    }
+    for (; t < T; t += 4) {
+      kstep(S0{}, t);
+      if (t + 1 < T) kstep(S1{}, t + 1);
+      if (t + 2 < T) kstep(S2{}, t + 2);
+      if (t + 3 < T) kstep(S3{}, t + 3);
     }
   }
 
@@ -479,15 +529,15 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_kernel(const ConvA
 #endif  // __HIP_DEVICE_COMPILE__
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int NS = 2>
 static hipError_t launch_cfg(const ConvArgs& a, hipStream_t s) {
   const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + BN - 1) / BN;
   if (a.dgrad)
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, true>), dim3(tiles_m * tiles_n), dim3(WM * WN * 64), 0, s, a,
-                       tiles_n);
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, true, NS>), dim3(tiles_m * tiles_n), dim3(WM * WN * 64), 0, s,
+                       a, tiles_n);
   else
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, false>), dim3(tiles_m * tiles_n), dim3(WM * WN * 64), 0, s, a,
-                       tiles_n);
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, false, NS>), dim3(tiles_m * tiles_n), dim3(WM * WN * 64), 0, s,
+                       a, tiles_n);
   return hipGetLastError();
 }
 
@@ -560,6 +610,12 @@ hipError_t vy_launch_conv_igemm(const ConvArgs& a_in, hipStream_t s) {
   select_cfg(a, &bm, &bn);
   if (bn == 32) return launch_cfg<128, 32, 4, 1>(a, s);
   if (bm == 128 && bn == 64) return launch_cfg<128, 64, 2, 2>(a, s);
-  if (bm == 64) return launch_cfg<64, 64, 2, 2>(a, s);
+  if (bm == 64) {
+    // few blocks (at most two per CU) and a k-loop long enough to fill it: the four-stage pipeline
+    static const int deep = getenv("VY_CONV_DEEP") ? atoi(getenv("VY_CONV_DEEP")) : 512;
+    const long long nb = (long long)((a.M + 63) / 64) * ((a.N + 63) / 64);
+    if (nb <= deep && a.ntaps * (a.Kc >> 5) >= 8) return launch_cfg<64, 64, 2, 2, 4>(a, s);
+    return launch_cfg<64, 64, 2, 2>(a, s);
+  }
   return launch_cfg<128, 128, 2, 2>(a, s);
 }
