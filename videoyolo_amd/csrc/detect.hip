@@ -328,18 +328,27 @@ __global__ __launch_bounds__(kHistThreads) void compact_kernel(const DetArgs d, 
     Item im;
     if (it >= n_items || !locate(d, b, it, im)) continue;
     const float* cache = sc.score + (size_t)b * d.C * n_items + it;
-    for (int c = 0; c < d.C; ++c) {
-      const float s = cache[(size_t)c * n_items];
-      if (!(s > d.valid_thresh)) continue;
-      const uint32_t bucket = score_bucket(s);
-      if (bucket < Tb) continue;
-      const uint32_t sbits = vy_f32_to_bits(s);
-      const uint32_t inv = ((1u << kIdxBits) - 1u) - (uint32_t)(im.cand0 + c * im.cstride);
-      if (bucket > Tb) {
-        put_entry(d, ent, stp, im, c, sbits, inv);
-      } else if (fits) {
-        const int slot = atomicAdd(&stp->list_n, 1);
-        if (slot < kListCap) list[slot] = ((unsigned long long)sbits << 32) | inv;
+    // eight classes' scores in flight per round trip (one load per iteration made the sweep latency-bound at small
+    // batches: 45 us for one frame's 1.8 MB)
+    for (int c0 = 0; c0 < d.C; c0 += 8) {
+      float s8[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s8[u] = (c0 + u < d.C) ? cache[(size_t)(c0 + u) * n_items] : 0.0f;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const float s = s8[u];
+        const int c = c0 + u;
+        if (c >= d.C || !(s > d.valid_thresh)) continue;
+        const uint32_t bucket = score_bucket(s);
+        if (bucket < Tb) continue;
+        const uint32_t sbits = vy_f32_to_bits(s);
+        const uint32_t inv = ((1u << kIdxBits) - 1u) - (uint32_t)(im.cand0 + c * im.cstride);
+        if (bucket > Tb) {
+          put_entry(d, ent, stp, im, c, sbits, inv);
+        } else if (fits) {
+          const int slot = atomicAdd(&stp->list_n, 1);
+          if (slot < kListCap) list[slot] = ((unsigned long long)sbits << 32) | inv;
+        }
       }
     }
   }
@@ -504,13 +513,24 @@ __global__ __launch_bounds__(kNmsThreads) void sort_nms_kernel(const DetArgs d, 
     const int words = (k + 31) >> 5;
     for (int idx = t; idx < k * words; idx += kNmsThreads) {
       const int i = idx / words, w = idx - i * words;
-      const float ax1 = bx1[i], ay1 = by1[i], ax2 = bx2[i], ay2 = by2[i], ac = bcls[i];
       uint32_t m = 0;
-      for (int bit = 0; bit < 32; ++bit) {
-        const int j = 32 * w + bit;
-        if (j > i && j < k && bcls[j] == ac &&
-            vy_box_iou(ax1, ay1, ax2, ay2, bx1[j], by1[j], bx2[j], by2[j]) > d.nms_thresh)
-          m |= 1u << bit;
+      if (32 * w + 31 > i) {  // words wholly at or before candidate i hold no j > i
+        const float ac = bcls[i];
+        // first the cheap part for all 32 candidates of the word — later, in range, same class — then the IoU only
+        // for the set bits: a wave pays for the longest list among its lanes, not for 32 divergent iterations
+        uint32_t cm = 0;
+#pragma unroll 8
+        for (int bit = 0; bit < 32; ++bit) {
+          const int j = 32 * w + bit;
+          cm |= (uint32_t)(j > i && j < k && bcls[j] == ac) << bit;
+        }
+        const float ax1 = bx1[i], ay1 = by1[i], ax2 = bx2[i], ay2 = by2[i];
+        while (cm) {
+          const int bit = __builtin_ctz(cm);
+          cm &= cm - 1;
+          const int j = 32 * w + bit;
+          if (vy_box_iou(ax1, ay1, ax2, ay2, bx1[j], by1[j], bx2[j], by2[j]) > d.nms_thresh) m |= 1u << bit;
+        }
       }
       mask[i][w] = m;
     }
@@ -518,10 +538,21 @@ __global__ __launch_bounds__(kNmsThreads) void sort_nms_kernel(const DetArgs d, 
     if (t < 64) {
       uint32_t aw = 0;
       if (t < words) aw = (32 * t + 32 <= k) ? 0xffffffffu : ((1u << (k - 32 * t)) - 1u);
-      for (int i = 0; i < k; ++i) {
-        const uint32_t wi = __shfl(aw, i >> 5);
-        if ((wi >> (i & 31)) & 1u)
-          if (t < words) aw &= ~mask[i][t];
+      // candidate i's alive bit lives in lane i / 32: a scalar-indexed v_readlane (a few cycles; __shfl would be a
+      // ds_bpermute round trip per candidate), and the mask rows of 16 candidates are read ahead of their use
+      const int tw = t < words ? t : 0;
+      for (int i0 = 0; i0 < k; i0 += 16) {
+        uint32_t mrow[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) mrow[u] = (i0 + u < k) ? mask[i0 + u][tw] : 0u;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+          const int i = i0 + u;  // rows past k were read as 0: no early exit, so that mrow[] stays in registers
+          // branch-free: the row is applied through an all-ones / all-zeros scalar (lanes >= words carry aw = 0)
+          const uint32_t wi = (uint32_t)__builtin_amdgcn_readlane((int)aw, i >> 5);
+          const uint32_t sel = 0u - ((wi >> (i & 31)) & 1u);
+          aw &= ~(mrow[u] & sel);
+        }
       }
       if (t < words)
         for (int bit = 0; bit < 32 && 32 * t + bit < k; ++bit) alive[32 * t + bit] = (uint8_t)((aw >> bit) & 1u);
