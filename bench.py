@@ -45,6 +45,17 @@ def _short_kernel_name(name):
     return name
 
 
+def _forward_tile_key(names, bm, bn):
+    """The counter file's name of the forward, double-buffered instance of a tile:
+    conv_igemm_kernel<BM, BN, WM, WN, DGRAD = false, NS = 2>."""
+    pre = "void conv_igemm_kernel<%s, %s," % (bm, bn)
+    for k in names:
+        args = k[k.find("<") + 1:k.rfind(">")].replace(" ", "").split(",") if k.startswith(pre) else []
+        if len(args) >= 5 and args[4] == "false" and (len(args) == 5 or args[5] == "2"):
+            return k
+    return None
+
+
 def measure_hbm_traffic(argv, steps_run):
     """HBM traffic of this very command, measured now: two extra child runs of bench.py under
     `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (separate passes, counters only, no tracing — the
@@ -245,8 +256,7 @@ def main():
         # HBM bytes per launch of the same kernel, measured by this run's two rocprofv3 --pmc child passes
         if traffic:
             tile = dom.split("<")[1].rstrip(">").split("x")
-            key = next((k for k in traffic if k.startswith("void conv_igemm_kernel<%s, %s," % (tile[0], tile[1]))
-                        and k.rstrip(">").endswith("false")), None)
+            key = _forward_tile_key(traffic, tile[0], tile[1])
             if key:
                 result["roofline"]["traffic"] = traffic[key]["hbm_bytes"]
                 result["roofline"]["traffic_detail"] = {

@@ -17,7 +17,7 @@ _FAKE = textwrap.dedent('''\
     counter, d = a[a.index("--pmc") + 1], a[a.index("-d") + 1]
     os.makedirs(os.path.join(d, "host"), exist_ok=True)
     rows = ["Correlation_Id,Dispatch_Id,Agent_Id,Queue_Id,Process_Id,Thread_Id,Grid_Size,Kernel_Id,Kernel_Name,Workgroup_Size,LDS_Block_Size,Scratch_Size,VGPR_Count,Accum_VGPR_Count,SGPR_Count,Counter_Name,Counter_Value,Start_Timestamp,End_Timestamp"]
-    conv = '"void conv_igemm_kernel<128, 128, 2, 2, false>(ConvArgs, int)"'
+    conv = '"void conv_igemm_kernel<128, 128, 2, 2, false, 2>(ConvArgs, int)"'
     vals = {"FETCH_SIZE": (1000.0, 3000.0), "WRITE_SIZE": (500.0, 700.0)}[counter]   # KiB per dispatch
     for i, v in enumerate(vals):
         rows.append("1,%d,0,1,1,1,256,7,%s,256,0,0,64,0,32,%s,%f,0,1" % (i + 1, conv, counter, v))
@@ -29,8 +29,8 @@ _FAKE = textwrap.dedent('''\
 
 def test_short_kernel_name():
     import bench
-    assert bench._short_kernel_name("void conv_igemm_kernel<128, 128, 2, 2, false>(ConvArgs, int)") == \
-        "void conv_igemm_kernel<128, 128, 2, 2, false>"
+    assert bench._short_kernel_name("void conv_igemm_kernel<128, 128, 2, 2, false, 2>(ConvArgs, int)") == \
+        "void conv_igemm_kernel<128, 128, 2, 2, false, 2>"
     assert bench._short_kernel_name("(anonymous namespace)::hist_kernel(DetArgs, void*, int, int)") == \
         "(anonymous namespace)::hist_kernel"
     assert bench._short_kernel_name("__amd_rocclr_copyBuffer") == "__amd_rocclr_copyBuffer"
@@ -44,7 +44,7 @@ def test_traffic_from_counter_files(tmp_path, monkeypatch):
     monkeypatch.setattr(bench, "ROCPROF", str(fake))
     out, note = bench.measure_hbm_traffic(["--steps", "1"], steps_run=2)
     assert note is None
-    k = out["void conv_igemm_kernel<128, 128, 2, 2, false>"]
+    k = out["void conv_igemm_kernel<128, 128, 2, 2, false, 2>"]
     assert k["launches"] == 2
     assert k["fetch_bytes"] == 2 * (1000.0 + 3000.0) * 1024 / 2          # KiB -> bytes, x2 (gfx950), mean per launch
     assert k["write_bytes"] == (500.0 + 700.0) * 1024 / 2
@@ -59,3 +59,13 @@ def test_traffic_reports_a_missing_profiler(monkeypatch):
     monkeypatch.setattr(bench, "ROCPROF", "/nonexistent/rocprofv3")
     out, note = bench.measure_hbm_traffic([], 1)
     assert out is None and "not found" in note
+
+
+def test_forward_tile_key_matches_both_template_signatures():
+    names = ["void conv_igemm_kernel<128, 128, 2, 2, true, 2>", "void conv_igemm_kernel<64, 64, 2, 2, false, 4>",
+             "void conv_igemm_kernel<64, 64, 2, 2, false, 2>", "void conv_igemm_kernel<128, 128, 2, 2, false, 2>",
+             "void conv_igemm_kernel<128, 64, 2, 2, false>", "sgd_kernel"]
+    assert bench._forward_tile_key(names, "128", "128") == "void conv_igemm_kernel<128, 128, 2, 2, false, 2>"
+    assert bench._forward_tile_key(names, "64", "64") == "void conv_igemm_kernel<64, 64, 2, 2, false, 2>"
+    assert bench._forward_tile_key(names, "128", "64") == "void conv_igemm_kernel<128, 64, 2, 2, false>"
+    assert bench._forward_tile_key(names, "128", "32") is None
