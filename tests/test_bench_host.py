@@ -62,6 +62,7 @@ def test_traffic_reports_a_missing_profiler(monkeypatch):
 
 
 def test_forward_tile_key_matches_both_template_signatures():
+    import bench
     names = ["void conv_igemm_kernel<128, 128, 2, 2, true, 2>", "void conv_igemm_kernel<64, 64, 2, 2, false, 4>",
              "void conv_igemm_kernel<64, 64, 2, 2, false, 2>", "void conv_igemm_kernel<128, 128, 2, 2, false, 2>",
              "void conv_igemm_kernel<128, 64, 2, 2, false>", "sgd_kernel"]
