@@ -17,7 +17,8 @@ for r in step:
     if n.startswith("void wgrad_kernel"):
         cls["wgrad"].append(r)
     elif n.startswith("void conv_igemm_kernel"):
-        cls["dgrad" if "true>" in n.split("(")[0] else "fwd"].append(r)
+        targs = n.split("(")[0].split("<")[1].rstrip(">").replace(" ", "").split(",")  # BM,BN,WM,WN,DGRAD[,NS]
+        cls["dgrad" if targs[4] == "true" else "fwd"].append(r)
 tot = {}
 for kind in ("fwd", "dgrad", "wgrad"):
     assert len(cls[kind]) == len(labels[kind]), (kind, len(cls[kind]), len(labels[kind]))
