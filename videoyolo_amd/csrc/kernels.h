@@ -194,6 +194,8 @@ struct WgradArgs {
   int splits, k_per_split;  // k_per_split pixels (multiple of 32) per split
 };
 hipError_t vy_launch_wgrad(const WgradArgs& a, hipStream_t s);
+// output rows (dz channels) of a weight-gradient block tile: 64 or 128 (the planner's split count depends on it)
+int vy_wgrad_tile_rows(int Cout, int k, int Cin);
 // per-pixel byte offsets (dz vector, input-plane centre pixel shifted by one row + one column) for vy_launch_wgrad;
 // n_entries = vy_wgrad_table_entries(M); both planes must be smaller than 4 GiB
 inline size_t vy_wgrad_table_entries(long long M) { return (size_t)((M + 31) / 32 * 32 + 32); }

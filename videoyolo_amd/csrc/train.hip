@@ -164,7 +164,8 @@ size_t train_plan(vy_net* net, int b, int h, int w, bool commit) {
     }
     if (!c.is_stem) {
       const int Ntot = c.k * c.k * c.cin;
-      const int tiles = ((c.cout + 127) / 128) * ((Ntot + 127) / 128);
+      const int rows = vy_wgrad_tile_rows(c.cout, c.k, c.cin);
+      const int tiles = ((c.cout + rows - 1) / rows) * ((Ntot + 127) / 128);
       // Split-K over the pixels.  A block runs k_per_split / 32 k-steps (+ ~3 k-steps worth of prologue and slab
       // store); the chip holds 512 blocks at a time (2 per CU), so the launch costs about
       // ceil(tiles * splits / 512) * (k_per_split / 32 + 3).  Round 1 took the smallest split count with >= 1024

@@ -221,13 +221,24 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a, const 
 #endif
 }
 
+// 64-row tiles for Cout <= 64 (no zero padding in the MFMA rows) and for weight tensors of so few 128-row tiles that
+// the planner would cut the pixel range into dozens of splits of 64 KB slabs: every 1x1 layer and tensors of at most
+// VY_WGRAD_BM64_TILES (8) 128-row tiles (measured in the step: +0.4 %; larger 3x3 tensors lose)
+int vy_wgrad_tile_rows(int Cout, int k, int Cin) {
+  static const int max_tiles = getenv("VY_WGRAD_BM64_TILES") ? atoi(getenv("VY_WGRAD_BM64_TILES")) : 8;
+  if (Cout <= 64) return 64;
+  if (max_tiles < 0) return 128;  // experiment switch: the round-1 rule
+  const int tiles128 = ((Cout + 127) / 128) * ((k * k * Cin + 127) / 128);
+  return (k == 1 || tiles128 <= max_tiles) ? 64 : 128;
+}
+
 hipError_t vy_launch_wgrad(const WgradArgs& a, hipStream_t s) {
   if (a.Cin % 32 != 0 || a.k_per_split % 32 != 0 || a.splits < 1 || (a.z_cs & 3) || (a.a_cs & 3) || (a.a_co & 3) || !a.tab)
     return hipErrorInvalidValue;
   const int Ntot = a.k * a.k * a.Cin;
   const int tiles_n = (Ntot + 127) / 128;
-  if (a.Cout <= 64)
-    hipLaunchKernelGGL((wgrad_kernel<32, 64>), dim3(tiles_n, a.splits), dim3(256), 0, s, a, tiles_n);
+  if (vy_wgrad_tile_rows(a.Cout, a.k, a.Cin) == 64)
+    hipLaunchKernelGGL((wgrad_kernel<32, 64>), dim3((a.Cout + 63) / 64 * tiles_n, a.splits), dim3(256), 0, s, a, tiles_n);
   else
     hipLaunchKernelGGL((wgrad_kernel<32, 128>), dim3((a.Cout + 127) / 128 * tiles_n, a.splits), dim3(256), 0, s, a,
                        tiles_n);
