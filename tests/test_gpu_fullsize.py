@@ -86,6 +86,38 @@ def test_inference_full_size(ncls, batch, obj_bias):
     np.testing.assert_allclose(bboxes[j:j + 1], r_bboxes, rtol=0, atol=1e-4)
 
 
+def test_inference_large_odd_size():
+    """A video-sized frame batch whose height and width are odd (609 x 611): ceil-sized feature maps, the cropped x2
+    upsample on both axes, the stem's unaligned-row path, the big conv tiles on ragged geometry.  Frame independence
+    inside the batch + one frame against the oracle (heads bit for bit, detections)."""
+    import torch
+    from videoyolo_amd import init
+    from oracle import yolo3_oracle as O
+    classes = ["c%d" % i for i in range(20)]
+    params = init.synthetic_params(O.param_shapes(20), seed=233, obj_bias=-4.0)
+    net = _net(classes, params)
+    rng = np.random.default_rng(3)
+    x = torch.as_tensor(rng.standard_normal((9, 3, 609, 611)).astype(np.float32)).cuda()
+    ids, scores, bboxes, keep = [t.cpu().numpy() for t in net(x, return_index=True)]
+    _check_nms_invariants(ids, scores, bboxes, 20, 0.45, 100)
+    j = 5
+    alone = [t.cpu().numpy() for t in net(x[j:j + 1], return_index=True)]
+    for full, one in zip((ids, scores, bboxes, keep), alone):
+        assert np.array_equal(full[j:j + 1], one)
+    orc = O.OracleYolo3(20, params)
+    xj = x[j:j + 1].cpu().numpy()
+    ref = orc.raw_heads(xj)
+    for i in range(3):  # the heads of the single-frame run just made
+        got = net.read_head(i).cpu().numpy()
+        assert got.shape == ref[i].shape == (1, 75, -(-609 // [32, 16, 8][i]), -(-611 // [32, 16, 8][i]))
+        assert np.array_equal(got, ref[i])
+    r_ids, r_scores, r_bboxes, r_keep = orc(xj)
+    assert np.array_equal(keep[j:j + 1], r_keep) and np.array_equal(ids[j:j + 1], r_ids)
+    np.testing.assert_allclose(scores[j:j + 1], r_scores, rtol=0, atol=1e-4)
+    fin = np.isfinite(r_bboxes)
+    np.testing.assert_allclose(bboxes[j:j + 1][fin], r_bboxes[fin], rtol=0, atol=1e-4)
+
+
 def test_training_full_size_step():
     """416x416, batch 16, 20 classes (configs[2]): determinism, a directional finite difference of the
     summed loss against <grad, d>, and the SGD update in closed form."""
