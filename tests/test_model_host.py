@@ -220,3 +220,26 @@ def test_trainer_uses_the_scheduler(voc_classes):
     assert tr.learning_rate == 1.0
     with pytest.raises(UserWarning):
         tr.set_learning_rate(0.5)
+
+
+def test_fastdiv_formula_is_exact():
+    """The conv kernel's row tables divide by the feature-map width / height with one multiply-high
+    (csrc/conv_igemm.hip make_fastdiv / fd_div): the same integer arithmetic, checked here against // for every
+    divisor a plan can produce and n across the 32-bit range."""
+    def make(d):
+        l = 0
+        while (1 << l) < d:
+            l += 1
+        return ((((1 << l) - d) << 32) // d + 1) & 0xffffffff, min(l, 1), max(l - 1, 0)
+
+    def div(n, f):
+        m, s1, s2 = f
+        t = (m * n) >> 32
+        return ((t + (((n - t) & 0xffffffff) >> s1)) & 0xffffffff) >> s2
+
+    rng = np.random.default_rng(0)
+    for d in list(range(1, 300)) + [304, 416, 608, 1024, 2048, 4095, 4096]:
+        f = make(d)
+        ns = [0, 1, d - 1, d, d + 1, 2 * d - 1, 2 ** 31 - 1, 2 ** 32 - 1] + [int(v) for v in rng.integers(0, 2 ** 32, 200)]
+        for n in ns:
+            assert div(n, f) == n // d, (n, d)

@@ -76,6 +76,11 @@ __device__ __forceinline__ void buf_store_f32(float v, __amdgpu_buffer_rsrc_t rs
 }
 #endif
 
+__device__ __forceinline__ unsigned fd_div(unsigned n, const VyFastDiv f) {
+  const unsigned t = __umulhi(f.m, n);
+  return (t + ((n - t) >> f.s1)) >> f.s2;
+}
+
 // workgroup barrier that waits for this wave's LDS traffic only (not for outstanding global loads: the deep
 // pipeline below keeps LDS-DMA of later k-steps in flight across it)
 __device__ __forceinline__ void lds_barrier() {
@@ -139,10 +144,10 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_kernel(const ConvA
   // output pixel of the tile's first row (m0 < M always): wave-uniform
   long long pix0;
   {
-    const int x = m0 % a.LW;
-    const int t = m0 / a.LW;
-    const int y = t % a.LH;
-    const int b = t / a.LH;
+    const int t = (int)fd_div((unsigned)m0, a.fd_lw);
+    const int x = m0 - t * a.LW;
+    const int b = (int)fd_div((unsigned)t, a.fd_lh);
+    const int y = t - b * a.LH;
     const long long p = (long long)(b * a.o_Hp + y * a.o_s + a.o_oy) * a.o_Wp + x * a.o_s + a.o_ox;
     pix0 = ((long long)__builtin_amdgcn_readfirstlane((int)(p >> 32)) << 32) |
            (unsigned)__builtin_amdgcn_readfirstlane((int)p);
@@ -150,10 +155,12 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_kernel(const ConvA
   for (int rr = tid; rr < BM; rr += NT) {
     const int m = m0 + rr;
     const int mm = m < a.M ? m : a.M - 1;
-    const int x = mm % a.LW;
-    const int t = mm / a.LW;
-    const int y = t % a.LH;
-    const int b = t / a.LH;
+    // (two multiply-highs instead of two emulated 32-bit divisions per row: the prologue is on the critical path of
+    // the short launches at small batches)
+    const int t = (int)fd_div((unsigned)mm, a.fd_lw);
+    const int x = mm - t * a.LW;
+    const int b = (int)fd_div((unsigned)t, a.fd_lh);
+    const int y = t - b * a.LH;
     in_off[rr] = ((long long)(b * a.a_Hp + y * a.a_s + a.a_oy) * a.a_Wp + x * a.a_s + a.a_ox) * a.a_cs + a.a_co;
     const unsigned rel = (unsigned)(((long long)(b * a.o_Hp + y * a.o_s + a.o_oy) * a.o_Wp + x * a.o_s + a.o_ox) - pix0);
     unsigned oo_row = (m < a.M) ? rel * (unsigned)a.o_cs * 4u : kInvalidRow;
@@ -590,8 +597,21 @@ int vy_conv_tiles_m(const ConvArgs& a) {
   return (a.M + bm - 1) / bm;
 }
 
+static VyFastDiv make_fastdiv(unsigned d) {
+  unsigned l = 0;
+  while ((1ull << l) < d) ++l;
+  VyFastDiv f;
+  f.m = (unsigned)((((1ull << l) - d) << 32) / d + 1);
+  f.s1 = l < 1 ? l : 1;
+  f.s2 = l > 0 ? l - 1 : 0;
+  return f;
+}
+
 hipError_t vy_launch_conv_igemm(const ConvArgs& a_in, hipStream_t s) {
   ConvArgs a = a_in;
+  if (a.LW < 1 || a.LH < 1) return hipErrorInvalidValue;
+  a.fd_lw = make_fastdiv((unsigned)a.LW);
+  a.fd_lh = make_fastdiv((unsigned)a.LH);
   a.pk_dy = a.pk_dx = 0;
   a.pk_w = 0;
   for (int t = 0; t < a.ntaps; ++t) {

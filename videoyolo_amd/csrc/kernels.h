@@ -12,6 +12,12 @@
 //   forward      A = input activations, W rows = Cout ([n][k] operand), taps = (kh-p, kw-p)
 //   dgrad        A = dz (gradient of the conv output), W read as [k = cout][n = cin], taps flipped;
 //                stride-2 convs run one launch per input-pixel parity class (o_s = 2)
+// exact n / d for any 32-bit n by one multiply-high (Granlund-Montgomery round-up): t = mulhi(m, n);
+// q = (t + ((n - t) >> s1)) >> s2
+struct VyFastDiv {
+  unsigned m, s1, s2;
+};
+
 struct ConvArgs {
   const float* in;      // A operand plane base
   const float* w;       // weights [Cout][taps][Cin]
@@ -33,6 +39,7 @@ struct ConvArgs {
   int r_cs, r_co;
   int leaky;            // LeakyReLU(0.1) after the affine
   int dgrad;            // 0: W is the [n][k] operand (forward); 1: W is the [k][n] operand (dgrad)
+  VyFastDiv fd_lw, fd_lh;       // filled by the launcher: division by LW / LH (the row tables of every tile)
   unsigned pk_dy, pk_dx;        // filled by the launcher: tap tables packed 2 bits / tap (value + 1)
 #ifdef VY_CONV_TRACE
   unsigned long long* trace;    // tools/probe/conv_tile_trace.hip only: [block][8] phase timestamps (100 MHz) + CU id
