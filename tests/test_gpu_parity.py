@@ -134,6 +134,41 @@ def test_class_counts_and_odd_batches(ncls, batch, size):
         assert np.array_equal(net.read_head(i).cpu().numpy(), heads[i])
 
 
+def _random_configs(n, seed):
+    rng = np.random.default_rng(seed)
+    out = []
+    for i in range(n):
+        out.append((int(rng.integers(1, 41)), int(rng.integers(1, 6)), int(rng.integers(32, 161)), int(rng.integers(32, 161)),
+                    float(rng.choice([0.3, 0.45, 0.6])), int(rng.choice([1, 17, 100, 400, 1000])), int(rng.choice([1, 10, 100])),
+                    float(rng.choice([0.0, -2.0, -4.0]))))
+    return out
+
+
+@pytest.mark.parametrize("ncls,batch,h,w,thr,topk,post,obj_bias", _random_configs(14, 2024))
+def test_random_configurations(ncls, batch, h, w, thr, topk, post, obj_bias):
+    """Seeded random draws over class count (1..40), batch (1..5), ANY height / width in [32, 160], NMS threshold, topk,
+    post_nms and objectness bias: heads bit for bit, detections and kept rows like the CPU checker."""
+    from videoyolo_amd import init
+    from oracle import yolo3_oracle as O
+    classes = ["c%d" % i for i in range(ncls)]
+    params = init.synthetic_params(O.param_shapes(ncls), seed=1000 + ncls, obj_bias=obj_bias)
+    rng = np.random.default_rng(h * 1000 + w)
+    x = rng.standard_normal((batch, 3, h, w)).astype(np.float32)
+    net = _net(classes, params)
+    net.set_nms(thr, topk, post)
+    ids, scores, bboxes, keep = [t.cpu().numpy() for t in net(x, return_index=True)]
+    orc = O.OracleYolo3(ncls, params, nms_thresh=thr, nms_topk=topk, post_nms=post)
+    heads = orc.raw_heads(x)
+    for i in range(3):
+        assert np.array_equal(net.read_head(i).cpu().numpy(), heads[i]), "head %d" % i
+    r = orc(x)
+    assert ids.shape == r[0].shape == (batch, post, 1)
+    assert np.array_equal(keep, r[3]) and np.array_equal(ids, r[0])
+    np.testing.assert_allclose(scores, r[1], rtol=0, atol=TOL)
+    fin = np.isfinite(r[2])
+    np.testing.assert_allclose(bboxes[fin], r[2][fin], rtol=0, atol=TOL)
+
+
 def test_ties_and_empty():
     """Degenerate inputs: all-zero weights give every candidate the SAME score (0.25): the order
     must fall back to the reference row index; a very negative objectness bias leaves no valid
