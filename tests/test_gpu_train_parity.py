@@ -80,6 +80,34 @@ def test_train_step_matches_oracle(C, B, S):
         assert np.abs(got - params[name]).max() > 0
 
 
+@pytest.mark.parametrize("C,B,H,W", [(5, 2, 64, 128), (3, 1, 160, 96)])
+def test_train_step_on_rectangular_frames(C, B, H, W):
+    """Height != width (multiples of 32): per-axis geometry in the target kernels, the weight-gradient pixel tables,
+    the stride-2 data gradients and the x2-summed transition gradients.  Losses and every gradient against the oracle."""
+    from videoyolo_amd import autograd, init
+    from oracle import targets_oracle as T
+    from oracle import yolo3_oracle as O
+    from oracle import yolo3_train_oracle as TO
+    params = init.synthetic_params(O.param_shapes(C), seed=23)
+    rng = np.random.default_rng(H + W)
+    x = rng.standard_normal((B, 3, H, W)).astype(np.float32)
+    gt_boxes, gt_ids = T.synthetic_gt(B, min(H, W), C, m=3, seed=4, pad_to=4)
+    tg = T.prefetch_targets(C, H, W, gt_boxes, gt_ids)
+    orc = TO.OracleYolo3Train(C, dict(params))
+    ref_losses = orc.forward_train(x, gt_boxes, *tg)
+    ref_grads = orc.backward()
+    net = _net(C, params)
+    with autograd.record():
+        losses = net(x, gt_boxes, *tg)
+        autograd.backward([losses[0] + losses[1] + losses[2] + losses[3]])
+    for got, want in zip(losses, ref_losses):
+        np.testing.assert_allclose(got.cpu().numpy(), want, rtol=1e-4, atol=1e-4)
+    for name, want in ref_grads.items():
+        got = net.grad(name)
+        err = np.abs(got - want).max() / (np.abs(want).max() + 1e-6)
+        assert err < 2e-3, (name, err)
+
+
 def test_train_options_and_inference_after_training():
     """label smoothing + no_wd / frozen backbone switches, then net(x) in inference mode on the same
     object (validate() after an epoch, train_yolov3.py:434-441)."""
