@@ -108,6 +108,34 @@ def test_train_step_on_rectangular_frames(C, B, H, W):
         assert err < 2e-3, (name, err)
 
 
+@pytest.mark.parametrize("thresh", [0.3, 0.9])
+def test_ignore_iou_thresh_reaches_the_dynamic_targets(thresh):
+    """YOLOV3T(ignore_iou_thresh=...) (yolo3.py:962) decides which unmatched predictions are ignored by the objectness
+    loss (yolo_target.py:204): a low and a high threshold against the oracle built with the same value — and the two
+    objectness losses differ, so the option is not a no-op."""
+    import videoyolo_amd as vy
+    from videoyolo_amd import autograd
+    from oracle import yolo3_train_oracle as TO
+    C, B, S = 4, 2, 96
+    params, x, gt_boxes, tg = _setup(C, B, S, m=4)
+    # raise the box-size predictions so that many predicted boxes overlap a ground-truth box
+    params = dict(params)
+    for i in range(3):
+        b = params["yolo_outputs.%d.prediction.bias" % i].copy().reshape(3, 5 + C)
+        b[:, 2:4] = 0.7
+        params["yolo_outputs.%d.prediction.bias" % i] = b.reshape(-1)
+    ref = TO.OracleYolo3Train(C, dict(params), ignore_iou_thresh=thresh).forward_train(x, gt_boxes, *tg)
+    base = TO.OracleYolo3Train(C, dict(params), ignore_iou_thresh=0.7).forward_train(x, gt_boxes, *tg)
+    net = vy.yolo3_darknet53(["c%d" % i for i in range(C)], pretrained_base=False, ignore_iou_thresh=thresh)
+    net.set_parameters(params)
+    net.collect_params().reset_ctx("cuda:0")
+    with autograd.record():
+        losses = net(x, gt_boxes, *tg)
+    for got, want in zip(losses, ref):
+        np.testing.assert_allclose(got.cpu().numpy(), want, rtol=1e-4, atol=1e-4)
+    assert np.abs(ref[0] - base[0]).max() > 1e-3, "the constructed case does not exercise the threshold"
+
+
 def test_train_options_and_inference_after_training():
     """label smoothing + no_wd / frozen backbone switches, then net(x) in inference mode on the same
     object (validate() after an epoch, train_yolov3.py:434-441)."""
