@@ -421,7 +421,9 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_kernel(const ConvA
       const int n = n0 + ncol;
       const bool nvalid = n < a.N;
       const int nc = nvalid ? n : a.N - 1;
-      const unsigned cmask = nvalid ? 0u : kInvalidRow;
+      // the lane's column offset with bit 31 set for a column past N; added to a row offset with a SATURATING add, so
+      // that "invalid row" + "invalid column" stays out of the descriptor's range (one instruction per address)
+      const unsigned colc = (unsigned)ncol * 4u | (nvalid ? 0u : kInvalidRow);
       float sc = 1.0f, sh = 0.0f;
       if (has_scale) sc = a.scale[nc];
       if (has_scale || has_shift) sh = a.shift[nc];
@@ -432,9 +434,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_kernel(const ConvA
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int row = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-          oo[r] = (o_off[row] + (unsigned)ncol * 4u) | cmask;
-          if (has_res)
-            rv[r] = buf_load_f32(res_rsrc, (r_off[row] + (unsigned)ncol * 4u) | cmask);
+          oo[r] = __builtin_elementwise_add_sat(o_off[row], colc);
+          if (has_res) rv[r] = buf_load_f32(res_rsrc, __builtin_elementwise_add_sat(r_off[row], colc));
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
