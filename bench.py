@@ -12,10 +12,18 @@ process per GPU: either the driver starts them (torch.distributed.run) or, run p
 (weak scaling, no data-path collective — SURVEY §8e "Inference"), the timed region is bracketed
 by barrier + synchronize and the max over ranks is reported.
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
-  roofline      the dominant kernel (the 128x128 implicit-GEMM conv) against the fp32 MFMA peak,
-                from HIP events recorded around every launch of one extra, un-timed pass
-  cpu_baseline  the CPU oracle (oracle/, a port — NOT MXNet) timed on a bounded sample
+Prints ONE JSON line on rank 0 (contract in the task statement) with extra objects:
+  roofline        the dominant kernel (the 128x128 implicit-GEMM conv) against the fp32 MFMA peak,
+                  from HIP events recorded around every launch of one extra, un-timed pass
+  cpu_baseline    the CPU oracle (oracle/, a port — NOT MXNet) timed on a bounded sample
+  cpu_baseline_torch  torch-CPU forward of the same conv graph (independent datapoint, NOT MXNet)
+  also_train416   BASELINE configs[2] at the same N: training step 416x416, 16 frames per GPU (recorded forward +
+                  backward + gradient all-reduce over RCCL, bucketed and overlapped + SGD), timed the same way
+                  (barrier + synchronize, max over ranks) — with the forward / backward / exposed-all-reduce split,
+                  the fraction of the fp32 MFMA roof and (N = 1) the HBM bytes per step
+  also_syncbn608  (N > 1) BASELINE configs[4]: 608x608, 8 frames per GPU, the net built with
+                  norm_layer=SyncBatchNorm, norm_kwargs={'num_devices': N} (train_yolov3.py:350-354), plus the
+                  246.5 MB gradient all-reduce timed alone and the fraction of it hidden behind backward
 """
 import argparse
 import json
@@ -56,6 +64,32 @@ def _forward_tile_key(names, bm, bn):
     return None
 
 
+_PROFILER_ENV_PREFIXES = ("ROCP_", "ROCPROF", "ROCPROFILER_", "ROCTRACER_", "HSA_TOOLS_", "ROCTX_")
+
+
+def under_profiler(env=None):
+    """True when this process runs inside rocprofv3 (or any HSA tool): its preloaded library has already
+    initialised the GPU, and a nested `rocprofv3 --pmc ... -- python` started from here would be a launcher that
+    re-execs under the outer profiler's LD_PRELOAD — the exec hop the pool forbids — and would mix counter
+    collection with the outer run's tracing."""
+    env = os.environ if env is None else env
+    if any(k.startswith(_PROFILER_ENV_PREFIXES) for k in env):
+        return True
+    return any(t in env.get("LD_PRELOAD", "") for t in ("rocprof", "roctracer", "rocprofiler"))
+
+
+def clean_child_env(env):
+    """The environment for a rocprofv3 child: no profiler settings inherited from whatever wraps this process."""
+    out = {k: v for k, v in env.items() if not k.startswith(_PROFILER_ENV_PREFIXES)}
+    pre = [t for t in out.get("LD_PRELOAD", "").split(":") if t and not any(
+        w in t for w in ("rocprof", "roctracer", "rocprofiler"))]
+    if pre:
+        out["LD_PRELOAD"] = ":".join(pre)
+    else:
+        out.pop("LD_PRELOAD", None)
+    return out
+
+
 def measure_hbm_traffic(argv, steps_run):
     """HBM traffic of this very command, measured now: two extra child runs of bench.py under
     `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (separate passes, counters only, no tracing — the
@@ -70,12 +104,14 @@ def measure_hbm_traffic(argv, steps_run):
     import tempfile
     if not os.path.exists(ROCPROF):
         return None, "rocprofv3 not found"
+    if under_profiler():
+        return None, "this process is itself being profiled (LD_PRELOAD / ROCP* in the environment): no nested rocprofv3"
     out = {}
     tmp = tempfile.mkdtemp(prefix="vy_pmc_", dir="/tmp")
     try:
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             d = os.path.join(tmp, counter)
-            env = dict(os.environ, VY_BENCH_CHILD="1", TMPDIR="/tmp")
+            env = dict(clean_child_env(os.environ), VY_BENCH_CHILD="1", TMPDIR="/tmp")
             cmd = [ROCPROF, "--pmc", counter, "--output-format", "csv", "-d", d, "--", sys.executable,
                    os.path.abspath(__file__)] + argv
             p = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=900)
@@ -108,6 +144,172 @@ def measure_hbm_traffic(argv, steps_run):
     return out, None
 
 
+FWD_GFLOP_PER_FRAME = {(416, 20): 65.43, (608, 20): 139.76, (608, 30): 139.92}  # SURVEY.md 8(d) / BASELINE.md 3
+
+
+def _barrier(dist, torch):
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+
+
+def _max_over_ranks(dt, dist, torch, dev):
+    if dist is None:
+        return dt
+    t = torch.tensor([dt], dtype=torch.float64, device=dev if dist.get_backend() != "gloo" else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def train_leg(vy, dev, dist, rank, world, size, batch, classes, steps, warmup, syncbn=False, overlap=True,
+              split=True, allreduce_alone=False):
+    """One training workload, timed like the headline: `warmup` un-timed steps, then exactly `steps` steps between
+    barrier + synchronize, max over ranks.  One step = recorded forward (batch-statistics BatchNorm, targets, loss)
+    + backward + gradient all-reduce (bucketed, overlapped with backward) + SGD: the call pattern of
+    train_yolov3.py:623-634.  syncbn: the net is built the way train_yolov3.py:350-354 builds it
+    (norm_layer=SyncBatchNorm, norm_kwargs={'num_devices': world}); with one rank that is plain BatchNorm.
+    EVERY rank runs this (it contains collectives); the returned dict is rank 0's view."""
+    import torch
+    from videoyolo_amd import autograd, targets
+    cls_names = ["c%d" % i for i in range(classes)]
+    kw = dict(norm_layer=vy.SyncBatchNorm, norm_kwargs={"num_devices": world}) if (syncbn and world > 1) else {}
+    net = vy.yolo3_darknet53(cls_names, pretrained_base=False, **kw)
+    net.initialize(init="synthetic", seed=233)
+    net.collect_params().reset_ctx(dev)
+    g = torch.Generator(device="cpu").manual_seed(1233 + rank)
+    x = torch.randn((batch, 3, size, size), generator=g, dtype=torch.float32).to(dev)
+    gt_boxes, gt_ids = targets.synthetic_gt(batch, size, classes, m=8, seed=100 + rank)
+    tg = targets.YOLOV3PrefetchTargetGenerator(classes)(size, size, gt_boxes, gt_ids)
+    dv = [torch.as_tensor(t).to(dev) for t in (gt_boxes,) + tuple(tg)]
+    trainer = vy.Trainer(net.collect_params(), 'sgd', {'learning_rate': 1e-3, 'wd': 5e-4, 'momentum': 0.9})
+    if world > 1 and overlap:
+        trainer.enable_overlap()
+    global_batch = batch * world
+
+    def step():
+        with autograd.record():
+            losses = net(x, *dv)
+            autograd.backward([losses[0] + losses[1] + losses[2] + losses[3]])
+        trainer.step(global_batch)
+        return losses
+
+    for _ in range(warmup):
+        step()
+    _barrier(dist, torch)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        losses = step()
+    _barrier(dist, torch)
+    dt = _max_over_ranks(time.perf_counter() - t0, dist, torch, dev)
+    fps = global_batch * steps / dt
+    fwd_gflop = FWD_GFLOP_PER_FRAME.get((size, classes))
+    out = {"frames_per_s": fps, "ms_per_step": 1e3 * dt / steps, "n_gpus": world, "per_gpu_batch": batch,
+           "global_batch": global_batch, "size": size, "classes": classes, "steps": steps, "warmup": warmup,
+           "batchnorm": "SyncBatchNorm(num_devices=%d) on the 6 layers that receive norm_layer" % world if kw else "per-device",
+           "allreduce": ("bucketed, overlapped with backward" if overlap else "one all-reduce after backward") if world > 1 else "none (1 rank)",
+           "loss_rank0": float(sum(l.sum() for l in losses).item() / batch)}
+    if fwd_gflop:
+        # whole timed step (forward + backward + exposed all-reduce + SGD) against the roof, per GPU
+        out["whole_step_tflops_per_gpu"] = fps / world * 3 * fwd_gflop / 1e3
+        out["frac"] = out["whole_step_tflops_per_gpu"] / FP32_MFMA_PEAK_TFLOPS
+    if split:
+        # extra un-timed steps split by events on the compute stream; EVERY rank runs them (collectives inside)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
+        rows = []
+        for _ in range(3):
+            ev[0].record()
+            with autograd.record():
+                losses = net(x, *dv)
+                ev[1].record()
+                autograd.backward([losses[0] + losses[1] + losses[2] + losses[3]])
+            ev[2].record()
+            trainer.allreduce_grads()   # overlapped: waits for the buckets still in flight; else the whole all-reduce
+            ev[3].record()
+            trainer.update(global_batch)
+            ev[4].record()
+            torch.cuda.synchronize()
+            rows.append([ev[i].elapsed_time(ev[i + 1]) for i in range(4)])
+        fw, bw, ar, up = [sorted(r[i] for r in rows)[1] for i in range(4)]
+        out.update(forward_ms=fw, backward_ms=bw, allreduce_exposed_ms=ar, sgd_ms=up)
+        if fwd_gflop:
+            fl = fwd_gflop * 1e9 * batch
+            out.update(forward_tflops=fl / (fw * 1e-3) / 1e12, backward_tflops=2 * fl / (bw * 1e-3) / 1e12,
+                       frac_forward_backward=3 * fl / ((fw + bw) * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS)
+    if allreduce_alone and world > 1:
+        # the flat gradient buffer (BASELINE.md 5: 246.5 MB) all-reduced with nothing else on the GPU
+        nbytes = net._grads.numel() * 4
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ts = []
+        for i in range(6):
+            _barrier(dist, torch)
+            e0.record()
+            dist.all_reduce(net._grads)
+            e1.record()
+            torch.cuda.synchronize()
+            if i:
+                ts.append(e0.elapsed_time(e1))
+        alone = sorted(ts)[len(ts) // 2]
+        out["allreduce_alone_ms"] = alone
+        out["allreduce_bytes"] = nbytes
+        out["allreduce_busbw_GBps"] = 2.0 * (world - 1) / world * nbytes / (alone * 1e-3) / 1e9
+        if split:
+            out["allreduce_overlap_fraction"] = max(0.0, min(1.0, 1.0 - out["allreduce_exposed_ms"] / alone))
+    del trainer, net
+    import gc
+    gc.collect()  # the net's ctypes callbacks hold a reference cycle: collect before returning its buffers
+    torch.cuda.empty_cache()
+    return out
+
+
+def torch_cpu_baseline(params, x, classes):
+    """torch-CPU forward of the same 75-conv graph (conv + eval BatchNorm + LeakyReLU, residuals, upsample + concat,
+    prediction convs): an independent CPU datapoint for BASELINE.md 4 — NOT the reference's MXNet path, and not the
+    checker (oracle/).  Decode + NMS (< 0.5 % of the work) are not included.  Returns seconds for len(x) frames."""
+    import torch
+    import torch.nn.functional as F
+    p = {k: torch.from_numpy(v) for k, v in params.items()}
+
+    def cell(t, pre, k, s):
+        t = F.conv2d(t, p[pre + ".0.weight"], None, s, k // 2)
+        t = F.batch_norm(t, p[pre + ".1.running_mean"], p[pre + ".1.running_var"], p[pre + ".1.gamma"],
+                         p[pre + ".1.beta"], False, 0.9, 1e-5)
+        return F.leaky_relu(t, 0.1)
+
+    def forward(t):
+        routes, idx = [], 0
+        stage_of = [(0, 15), (15, 24), (24, 29)]
+        feats = [("c", 1)]
+        for n in (1, 2, 8, 8, 4):
+            feats += [("c", 2)] + [("b", 0)] * n
+        for si, (lo, hi) in enumerate(stage_of):
+            for j, f in enumerate(feats[lo:hi]):
+                pre = "stages.%d.%d" % (si, j)
+                if f[0] == "c":
+                    t = cell(t, pre, 3, f[1])
+                else:
+                    t = t + cell(cell(t, pre + ".body.0", 1, 1), pre + ".body.1", 3, 1)
+            routes.append(t)
+        outs, t = [], routes[2]
+        for i in range(3):
+            for j in range(5):
+                t = cell(t, "yolo_blocks.%d.body.%d" % (i, j), 1 if j % 2 == 0 else 3, 1)
+            tip = cell(t, "yolo_blocks.%d.tip" % i, 3, 1)
+            outs.append(F.conv2d(tip, p["yolo_outputs.%d.prediction.weight" % i], p["yolo_outputs.%d.prediction.bias" % i]))
+            if i == 2:
+                break
+            t = F.interpolate(cell(t, "transitions.%d" % i, 1, 1), scale_factor=2, mode="nearest")
+            r = routes[1 - i]
+            t = torch.cat([t[:, :, :r.shape[2], :r.shape[3]], r], 1)
+        return outs
+
+    xt = torch.from_numpy(x)
+    with torch.no_grad():
+        forward(xt[:1])  # warm-up (thread pool, primitive caches)
+        t0 = time.perf_counter()
+        forward(xt)
+        return time.perf_counter() - t0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -121,16 +323,23 @@ def main():
     ap.add_argument("--cpu-frames", type=int, default=4, help="frames of the CPU-oracle sample (0: skip)")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--mode", choices=["infer", "train"], default="infer",
-                    help="infer: BASELINE configs[1] (default); train: configs[2] (416x416, batch 16/GPU, "
-                         "fwd + bwd + gradient all-reduce + SGD)")
+                    help="infer: BASELINE configs[1] headline + the training legs (default); train: configs[2] as the "
+                         "headline (416x416, batch 16/GPU, fwd + bwd + gradient all-reduce + SGD)")
     ap.add_argument("--syncbn", action="store_true", help="train: SyncBatchNorm statistics all-reduce (configs[4])")
     ap.add_argument("--no-overlap", action="store_true", help="train: all-reduce after backward instead of bucketed")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL over xGMI)")
     ap.add_argument("--share-gpu", action="store_true",
                     help="testing only: all ranks use cuda:0 (with --backend gloo) to exercise the N>1 code path on one GPU")
     ap.add_argument("--no-pmc", action="store_true",
-                    help="skip the two rocprofv3 --pmc child runs that measure roofline.traffic (N = 1 only)")
+                    help="skip the rocprofv3 --pmc child runs that measure roofline.traffic (N = 1 only)")
     ap.add_argument("--no-latency", action="store_true", help="skip the batch-1 latency figure (N = 1 inference only)")
+    ap.add_argument("--no-train-legs", action="store_true",
+                    help="infer mode: skip also_train416 / also_syncbn608 (BASELINE configs[2] / [4])")
+    ap.add_argument("--train-steps", type=int, default=10, help="timed steps of each training leg")
+    ap.add_argument("--train-size", type=int, default=416)
+    ap.add_argument("--train-batch", type=int, default=16, help="frames per GPU of also_train416")
+    ap.add_argument("--syncbn-size", type=int, default=608)
+    ap.add_argument("--syncbn-batch", type=int, default=8, help="frames per GPU of also_syncbn608")
     args = ap.parse_args()
     # `python bench.py --gpus N` (no rank environment): this process only starts the N ranks and waits —
     # it never touches a GPU and never execs (videoyolo_amd/launch.py).  Under torch.distributed.run the
@@ -143,15 +352,22 @@ def main():
             args.size = 416
         if "--batch" not in " ".join(sys.argv):
             args.batch = 16
-    # roofline.traffic is MEASURED by this run (not read from a committed file): at N = 1 two child runs of the
-    # same workload under rocprofv3 --pmc, before this process touches the GPU
-    traffic, traffic_note = None, "not measured (--no-pmc / --no-roofline / N > 1)"
+    legs = args.mode == "infer" and not args.no_train_legs
+    # roofline.traffic is MEASURED by this run (not read from a committed file): at N = 1 child runs of the
+    # same workloads under rocprofv3 --pmc, before this process touches the GPU
+    traffic, traffic_note = None, "not measured (--no-pmc / --no-roofline / N > 1 / inside a profiler)"
+    train_traffic, train_traffic_note = None, traffic_note
     in_child = bool(os.environ.get("VY_BENCH_CHILD"))
     if args.gpus == 1 and "WORLD_SIZE" not in os.environ and not in_child and not args.no_pmc and not args.no_roofline:
+        quiet = ["--steps", "2", "--warmup", "1", "--cpu-frames", "0", "--no-roofline", "--no-pmc", "--no-latency",
+                 "--no-train-legs"]
         child = ["--mode", args.mode, "--size", str(args.size), "--batch", str(args.batch), "--classes",
-                 str(args.classes), "--obj-bias", str(args.obj_bias), "--steps", "2", "--warmup", "1",
-                 "--cpu-frames", "0", "--no-roofline", "--no-pmc", "--no-latency"]
+                 str(args.classes), "--obj-bias", str(args.obj_bias)] + quiet
         traffic, traffic_note = measure_hbm_traffic(child, 3)
+        if legs:
+            child = ["--mode", "train", "--size", str(args.train_size), "--batch", str(args.train_batch), "--classes",
+                     str(args.classes)] + quiet
+            train_traffic, train_traffic_note = measure_hbm_traffic(child, 3)
 
     import numpy as np
     import torch
@@ -173,6 +389,9 @@ def main():
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
 
+    if args.mode == "train":
+        return bench_train(args, vy, dev, dist, rank, world, traffic, traffic_note)
+
     classes = ["c%d" % i for i in range(args.classes)]
     net = vy.yolo3_darknet53(classes, pretrained_base=False)
     net.initialize(init="synthetic", seed=233, obj_bias=args.obj_bias)
@@ -182,26 +401,14 @@ def main():
     g = torch.Generator(device="cpu").manual_seed(233 + rank)
     x = torch.randn((args.batch, 3, args.size, args.size), generator=g, dtype=torch.float32).to(dev)
 
-    if args.mode == "train":
-        return bench_train(args, vy, net, x, dev, dist, rank, world, traffic, traffic_note)
-
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
     for _ in range(args.warmup):
         net(x)
-    barrier()
+    _barrier(dist, torch)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = net(x)
-    barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    _barrier(dist, torch)
+    dt = _max_over_ranks(time.perf_counter() - t0, dist, torch, dev)
     frames = args.batch * world * args.steps
     fps = frames / dt
 
@@ -275,7 +482,8 @@ def main():
                 "ms": tail[1], "algorithmic_GBps": tail[3] / (tail[1] * 1e-3) / 1e9, "hbm_peak_GBps": HBM_PEAK_GBS}
 
     if rank == 0 and world == 1 and not args.no_latency:
-        # single-frame latency of the same path (the floor a video stream sees): eager and as a replayed HIP graph
+        # single-frame latency of the same path (the reference's default detect call: batch_size 1,
+        # detect_yolo3.py:55,209-222): eager and as a replayed HIP graph
         lat = {}
         x1 = x[:1].contiguous()
         for label, hyb in (("eager", False), ("hip_graph", True)):
@@ -289,6 +497,9 @@ def main():
             torch.cuda.synchronize()
             lat[label + "_ms"] = 1e3 * (time.perf_counter() - t0) / 30
         net.hybridize(False)
+        gf = FWD_GFLOP_PER_FRAME.get((args.size, args.classes))
+        if gf:
+            lat["frac_of_fp32_mfma_peak"] = gf / min(lat["eager_ms"], lat["hip_graph_ms"]) / FP32_MFMA_PEAK_TFLOPS
         result["latency_batch1"] = dict(lat, size=args.size, note="one frame resident in HBM -> 100 detection rows")
 
     if rank == 0 and world == 1 and not args.no_latency and args.size == 608:
@@ -303,7 +514,7 @@ def main():
         torch.cuda.synchronize()
         dt4 = time.perf_counter() - t0
         fps4 = args.batch * args.steps / dt4
-        gflop4 = 65.43 if args.classes == 20 else None  # forward GFLOP per 416x416 frame, 20 classes
+        gflop4 = FWD_GFLOP_PER_FRAME.get((416, args.classes))
         result["also_416"] = {"frames_per_s": fps4, "ms_per_step": 1e3 * dt4 / args.steps, "batch": args.batch,
                               "whole_step_tflops": None if gflop4 is None else fps4 * gflop4 / 1e3,
                               "frac_of_fp32_mfma_peak": None if gflop4 is None else fps4 * gflop4 / 1e3 / FP32_MFMA_PEAK_TFLOPS}
@@ -324,6 +535,45 @@ def main():
             "kind": "port",
             "sample": "%d frames of the same %dx%d batch through oracle/ (C + OpenMP conv, numpy graph, "
                       "C NMS); MXNet itself is not installable here" % (args.cpu_frames, args.size, args.size)}
+        try:
+            tdt = torch_cpu_baseline(params, xs, args.classes)
+            result["cpu_baseline_torch"] = {
+                "value": args.cpu_frames / tdt, "unit": "frames/s", "cores": int(torch.get_num_threads()),
+                "kind": "independent", "sample": "the same %d frames through torch-CPU conv2d / batch_norm / leaky_relu of the "
+                "same 75-conv graph (no decode / NMS); an independent CPU datapoint, NOT MXNet and not the checker"
+                % args.cpu_frames}
+        except Exception as e:  # a second datapoint: never fail the line for it
+            result["cpu_baseline_torch"] = {"value": None, "note": "%s: %s" % (type(e).__name__, e)}
+        del orc, params
+
+    if legs:
+        # BASELINE configs[2] (and [4] when N > 1) on the same ranks, timed the same way: all ranks enter.
+        # The inference net's buffers are released first (each leg builds its own net).
+        del net, x, out
+        torch.cuda.empty_cache()
+        leg = train_leg(vy, dev, dist, rank, world, args.train_size, args.train_batch, args.classes,
+                        args.train_steps, args.warmup, syncbn=False, overlap=True, allreduce_alone=True)
+        leg["workload"] = ("BASELINE.json configs[2]: training step, VOC-shape synthetic (%d cls, 8 gt/img), %dx%d, "
+                           "per-GPU batch %d, SGD(1e-3, 0.9, 5e-4), per-device BN, gradient all-reduce over %d rank(s)"
+                           % (args.classes, args.train_size, args.train_size, args.train_batch, world))
+        if train_traffic:
+            leg["traffic"] = train_traffic["_per_step"]
+            top = sorted(((k, v) for k, v in train_traffic.items() if isinstance(v, dict) and "rocclr" not in k and "at::native" not in k),
+                         key=lambda kv: -kv[1]["hbm_bytes"] * kv[1]["launches"])[:6]
+            leg["traffic_detail"] = {
+                "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child runs of `bench.py --mode train` (FETCH x2: gfx950); HBM bytes per step, all library kernels",
+                "top_kernels_MB_per_step": {k[:56]: round(v["hbm_bytes"] * v["launches"] / 3.0 / 1e6, 1) for k, v in top}}
+        else:
+            leg["traffic"] = None
+            leg["traffic_note"] = train_traffic_note
+        result["also_train416"] = leg
+        if world > 1:
+            leg = train_leg(vy, dev, dist, rank, world, args.syncbn_size, args.syncbn_batch, args.classes,
+                            args.train_steps, args.warmup, syncbn=True, overlap=True, allreduce_alone=False)
+            leg["workload"] = ("BASELINE.json configs[4]: SyncBN training step, %dx%d, per-GPU batch %d, net built with "
+                               "norm_layer=SyncBatchNorm, norm_kwargs={'num_devices': %d}; statistics + gradient all-reduce "
+                               "over %d ranks" % (args.syncbn_size, args.syncbn_size, args.syncbn_batch, world, world))
+            result["also_syncbn608"] = leg
 
     if rank == 0:
         print(json.dumps(result))
@@ -332,85 +582,35 @@ def main():
         dist.destroy_process_group()
 
 
-def bench_train(args, vy, net, x, dev, dist, rank, world, traffic=None, traffic_note=None):
-    """BASELINE configs[2]/[4]: one step = recorded forward (batch-stat BN, targets, loss) + backward +
-    gradient all-reduce (RCCL, bucketed and overlapped with backward) + SGD update."""
-    import numpy as np
-    import torch
-    from videoyolo_amd import autograd, parallel, targets
-    gt_boxes, gt_ids = targets.synthetic_gt(args.batch, args.size, args.classes, m=8, seed=100 + rank)
-    tg = targets.YOLOV3PrefetchTargetGenerator(args.classes)(args.size, args.size, gt_boxes, gt_ids)
-    dv = [torch.as_tensor(t).to(dev) for t in (gt_boxes,) + tuple(tg)]
-    trainer = vy.Trainer(net.collect_params(), 'sgd', {'learning_rate': 1e-3, 'wd': 5e-4, 'momentum': 0.9})
-    if world > 1 and not args.no_overlap:
-        trainer.enable_overlap()
-    if args.syncbn and world > 1:
-        parallel.SyncBatchNormHook(net)
-    global_batch = args.batch * world
-
-    def step():
-        with autograd.record():
-            losses = net(x, *dv)
-            autograd.backward([losses[0] + losses[1] + losses[2] + losses[3]])
-        trainer.step(global_batch)
-        return losses
-
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        losses = step()
-    barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    fps = global_batch * args.steps / dt
-    fwd_gflop = {416: 65.43, 608: 139.76}.get(args.size)
+def bench_train(args, vy, dev, dist, rank, world, traffic=None, traffic_note=None):
+    """--mode train: BASELINE configs[2]/[4] as the headline line (see train_leg)."""
+    leg = train_leg(vy, dev, dist, rank, world, args.size, args.batch, args.classes, args.steps, args.warmup,
+                    syncbn=args.syncbn, overlap=not args.no_overlap, split=not args.no_roofline,
+                    allreduce_alone=not args.no_roofline)
     result = {
         "metric": "frames/sec, yolo3_darknet53 training %dx%d" % (args.size, args.size),
-        "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
+        "value": leg["frames_per_s"], "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": leg["ms_per_step"], "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "BASELINE.json configs[%d]: training step, VOC-shape synthetic (%d cls, 8 gt/img), "
                                "%dx%d, per-GPU batch %d, SGD(1e-3, 0.9, 5e-4), %s BN, gradient all-reduce over %d rank(s)"
                                % (4 if args.syncbn else 2, args.classes, args.size, args.size, args.batch,
                                   "Sync" if args.syncbn else "per-device", world),
-                   "per_gpu_batch": args.batch, "global_batch": global_batch, "size": args.size,
-                   "classes": args.classes, "parallelism": "dp%d" % world,
-                   "loss_rank0": float(sum(l.sum() for l in losses).item() / args.batch)},
+                   "per_gpu_batch": args.batch, "global_batch": leg["global_batch"], "size": args.size,
+                   "classes": args.classes, "parallelism": "dp%d" % world, "loss_rank0": leg["loss_rank0"]},
     }
-    if not args.no_roofline and fwd_gflop:
-        # extra un-timed steps split into forward / backward / update by events; EVERY rank runs them (they
-        # contain the gradient and SyncBN collectives), rank 0 reports its own split
-        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
-        fw, bw, up = [], [], []
-        for _ in range(3):
-            ev[0].record()
-            with autograd.record():
-                losses = net(x, *dv)
-                ev[1].record()
-                autograd.backward([losses[0] + losses[1] + losses[2] + losses[3]])
-            ev[2].record()
-            trainer.step(global_batch)
-            ev[3].record()
-            torch.cuda.synchronize()
-            fw.append(ev[0].elapsed_time(ev[1])); bw.append(ev[1].elapsed_time(ev[2])); up.append(ev[2].elapsed_time(ev[3]))
-        fw, bw, up = sorted(fw)[1], sorted(bw)[1], sorted(up)[1]
-        fl = fwd_gflop * 1e9 * args.batch
+    if "forward_ms" in leg and "frac_forward_backward" in leg:
+        fw, bw = leg["forward_ms"], leg["backward_ms"]
         result["roofline"] = {
-            "bound": "mfma", "achieved": 3 * fl / ((fw + bw) * 1e-3) / 1e12, "peak": FP32_MFMA_PEAK_TFLOPS,
-            "unit": "TFLOP/s", "frac": 3 * fl / ((fw + bw) * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+            "bound": "mfma", "achieved": leg["frac_forward_backward"] * FP32_MFMA_PEAK_TFLOPS, "peak": FP32_MFMA_PEAK_TFLOPS,
+            "unit": "TFLOP/s", "frac": leg["frac_forward_backward"], "frac_whole_step": leg.get("frac"), "traffic": None,
             "kernel": "training step: conv_igemm (forward + dgrad) and wgrad_kernel; algorithmic FLOPs = 3 x forward",
-            "forward_ms": fw, "backward_ms": bw, "allreduce_sgd_ms": up,
-            "forward_tflops": fl / (fw * 1e-3) / 1e12, "backward_tflops": 2 * fl / (bw * 1e-3) / 1e12}
+            "forward_ms": fw, "backward_ms": bw, "allreduce_exposed_ms": leg["allreduce_exposed_ms"], "sgd_ms": leg["sgd_ms"],
+            "allreduce_sgd_ms": leg["allreduce_exposed_ms"] + leg["sgd_ms"],
+            "forward_tflops": leg["forward_tflops"], "backward_tflops": leg["backward_tflops"]}
+        for k in ("allreduce_alone_ms", "allreduce_busbw_GBps", "allreduce_overlap_fraction"):
+            if k in leg:
+                result["roofline"][k] = leg[k]
         if traffic:
             # HBM bytes of ONE training step, all library kernels (measured: see measure_hbm_traffic)
             result["roofline"]["traffic"] = traffic["_per_step"]

@@ -31,6 +31,7 @@ def main():
     ap.add_argument("--size", type=int, default=64)
     ap.add_argument("--per-rank", type=int, default=2)
     ap.add_argument("--classes", type=int, default=3)
+    ap.add_argument("--multiscale", action="store_true", help="phase C: a second recorded step at size + 32")
     args = ap.parse_args()
 
     import numpy as np
@@ -57,8 +58,8 @@ def main():
     mine = [x[sl], gt_boxes[sl]] + [t[sl] for t in tg]
     out = {}
 
-    def make_net():
-        net = vy.yolo3_darknet53(["c%d" % i for i in range(C)], pretrained_base=False)
+    def make_net(**kw):
+        net = vy.yolo3_darknet53(["c%d" % i for i in range(C)], pretrained_base=False, **kw)
         # every rank draws DIFFERENT weights (as an unseeded net.initialize() would): rank 0's must win
         net.initialize(init="synthetic", seed=17 + 100 * rank)
         net.collect_params().reset_ctx(dev)
@@ -83,7 +84,7 @@ def main():
     g_overlap = net._grads.clone()
     for n in RUNNING:                                   # after ONE recorded forward
         out["A_running/" + n] = net.collect_params()[n].data()
-    out["A_buckets"] = np.array(trainer._overlap.launched, np.int64)
+    out["A_buckets"] = np.array(trainer._overlap.last_launched, np.int64)
     trainer.disable_overlap()
     fwd_bwd(net)
     trainer.allreduce_grads()
@@ -94,12 +95,15 @@ def main():
         out["A_grad/" + n] = net.grad(n)
     del net, trainer, g_overlap
 
-    # ---- B. SyncBatchNorm + one full Trainer.step
-    net = make_net()
+    # ---- B. SyncBatchNorm + one full Trainer.step.  The net is built ONLY through the constructor argument, the way
+    # train_yolov3.py:350-354 does it: no explicit hook — the first recorded forward installs the exchange
+    net = make_net(norm_layer=vy.SyncBatchNorm, norm_kwargs={"num_devices": world})
     trainer = vy.Trainer(net.collect_params(), 'sgd', {'learning_rate': 1e-3, 'wd': 5e-4, 'momentum': 0.9})
     trainer.enable_overlap()
-    hook = parallel.SyncBatchNormHook(net)
+    assert net._sync_hook is None
     out["B_losses"] = fwd_bwd(net)
+    hook = net._sync_hook
+    assert hook is not None, "norm_layer=SyncBatchNorm did not install the statistics exchange"
     trainer.allreduce_grads()
     for n in WATCH:
         out["B_grad/" + n] = net.grad(n)
@@ -117,7 +121,37 @@ def main():
     trainer.step(B)
     out["B_losses2"] = np.stack([l.cpu().numpy() for l in losses])
     out["B_param2/stages.0.0.0.weight"] = net.collect_params()["stages.0.0.0.weight"].data()
+    out["B_sync_calls_step2"] = np.array(hook.calls, np.int64)     # the log covers one step, it does not grow
     torch.cuda.synchronize()
+    del net, trainer, hook
+
+    # ---- C. multi-scale under the hook and the bucket overlap (train_yolov3.py:258-271 trains at 320..608): a
+    # recorded step at S, then one at S + 32 — the workspace is re-planned (and re-allocated: it grows) in between;
+    # the statistics callback and the gradient buckets must follow it.  No update in between, so the second step is
+    # comparable with the oracle on the original parameters.
+    if args.multiscale:
+        S2 = S + 32
+        x2 = frames(B, S2, seed=9)
+        gt2, ids2 = T.synthetic_gt(B, S2, C, m=3, seed=5, pad_to=4)
+        tg2 = T.prefetch_targets(C, S2, S2, gt2, ids2)
+        mine2 = [x2[sl], gt2[sl]] + [t[sl] for t in tg2]
+        net = make_net(norm_layer=vy.SyncBatchNorm, norm_kwargs={"num_devices": world})
+        trainer = vy.Trainer(net.collect_params(), 'sgd', {'learning_rate': 1e-3, 'wd': 5e-4, 'momentum': 0.9})
+        trainer.enable_overlap()
+        fwd_bwd(net)
+        trainer.allreduce_grads()
+        ws1 = (net._ws.data_ptr(), net._ws.numel())
+        with autograd.record():
+            losses = net(*mine2)
+            autograd.backward([losses[0] + losses[1] + losses[2] + losses[3]])
+        trainer.allreduce_grads()
+        out["C_losses"] = np.stack([l.cpu().numpy() for l in losses])
+        out["C_replanned"] = np.array(net._ws.numel() > ws1[1])
+        out["C_sync_calls"] = np.array(net._sync_hook.calls, np.int64)
+        out["C_buckets"] = np.array(trainer._overlap.last_launched, np.int64)
+        for n in WATCH:
+            out["C_grad/" + n] = net.grad(n)
+        torch.cuda.synchronize()
     np.savez(os.path.join(args.outdir, "rank%d.npz" % rank), **out)
     dist.barrier()
     dist.destroy_process_group()

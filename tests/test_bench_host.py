@@ -70,3 +70,28 @@ def test_forward_tile_key_matches_both_template_signatures():
     assert bench._forward_tile_key(names, "64", "64") == "void conv_igemm_kernel<64, 64, 2, 2, false, 2>"
     assert bench._forward_tile_key(names, "128", "64") == "void conv_igemm_kernel<128, 64, 2, 2, false>"
     assert bench._forward_tile_key(names, "128", "32") is None
+
+
+def test_no_nested_profiler():
+    """bench.py inside rocprofv3 must not start its own rocprofv3 children, and the children it does start must not
+    inherit profiler settings."""
+    import bench
+    assert not bench.under_profiler({"PATH": "/usr/bin", "LD_PRELOAD": "/lib/libfoo.so"})
+    assert bench.under_profiler({"LD_PRELOAD": "/opt/rocm/lib/librocprofiler-sdk-tool.so"})
+    assert bench.under_profiler({"ROCP_TOOL_LIBRARIES": "x"}) and bench.under_profiler({"ROCPROF_OUTPUT_PATH": "/tmp"})
+    env = bench.clean_child_env({"PATH": "p", "ROCP_TOOL_LIBRARIES": "x", "ROCPROFILER_REGISTER_FORCE_LOAD": "1",
+                                 "HSA_TOOLS_LIB": "libx.so", "HSA_ENABLE_IPC_MODE_LEGACY": "0",
+                                 "LD_PRELOAD": "/opt/rocm/lib/librocprofiler-sdk-tool.so:/lib/libfoo.so"})
+    assert env == {"PATH": "p", "HSA_ENABLE_IPC_MODE_LEGACY": "0", "LD_PRELOAD": "/lib/libfoo.so"}
+    assert "LD_PRELOAD" not in bench.clean_child_env({"LD_PRELOAD": "/x/librocprofiler-sdk-tool.so"})
+
+
+def test_traffic_is_skipped_inside_a_profiler(monkeypatch, tmp_path):
+    import bench
+    fake = tmp_path / "rocprofv3"
+    fake.write_text(_FAKE)
+    fake.chmod(fake.stat().st_mode | stat.S_IEXEC)
+    monkeypatch.setattr(bench, "ROCPROF", str(fake))
+    monkeypatch.setenv("ROCP_TOOL_LIBRARIES", "/opt/rocm/lib/librocprofiler-sdk-tool.so")
+    out, note = bench.measure_hbm_traffic(["--steps", "1"], steps_run=2)
+    assert out is None and "profiled" in note

@@ -41,7 +41,8 @@ def ranks(case, tmp_path_factory):
     C, S, PB = case
     out = tmp_path_factory.mktemp("dp")
     rc = launch.spawn_ranks(WORLD, [os.path.join(ROOT, "tests", "dp_worker.py"), str(out), "--backend", "gloo",
-                                    "--share-gpu", "--size", str(S), "--per-rank", str(PB), "--classes", str(C)],
+                                    "--share-gpu", "--size", str(S), "--per-rank", str(PB), "--classes", str(C)]
+                            + (["--multiscale"] if S <= 96 else []),
                             timeout=1500)
     assert rc == 0, "a rank failed (exit code %d)" % rc
     return [dict(np.load(str(out / ("rank%d.npz" % r)))) for r in range(WORLD)]
@@ -122,6 +123,7 @@ def test_syncbn_step_matches_the_oracle(ranks, problem):
         calls = r["B_sync_calls"]
         # one exchange of [2][C] doubles per SyncBatchNorm layer and direction: stem 32 .. stages.2.0 1024
         assert len(calls) == 12 and sorted(set(calls.tolist())) == [64, 128, 256, 512, 1024, 2048]
+        assert len(r["B_sync_calls_step2"]) == 12     # per-step log: it does not grow with the number of steps
     # synchronised layers share their running statistics, per-device layers do not
     assert np.array_equal(ranks[0]["B_running/stages.0.1.1.running_var"], ranks[1]["B_running/stages.0.1.1.running_var"])
     assert np.array_equal(ranks[0]["B_running/stages.1.0.1.running_mean"], ranks[1]["B_running/stages.1.0.1.running_mean"])
@@ -142,12 +144,47 @@ def test_syncbn_step_matches_the_oracle(ranks, problem):
     assert np.isfinite(ranks[0]["B_losses2"]).all()
 
 
+def test_multiscale_step_under_the_hook_and_the_overlap(ranks, problem):
+    """A recorded step at S, then one at S + 32 on the same net (SyncBatchNorm from the constructor argument, bucketed
+    overlap on): the re-planned (larger) workspace is what the statistics callback and the buckets see — the second
+    step's losses and gradients against the oracle's SyncBN mode at the new size, 12 exchanges, 4 buckets."""
+    from oracle import targets_oracle as T
+    from oracle import yolo3_train_oracle as TO
+    params, _, _, _, (C, S, PB) = problem
+    if "C_losses" not in ranks[0]:
+        pytest.skip("full-size case runs without the multi-scale phase")
+    B, S2 = PB * WORLD, S + 32
+    x2 = frames(B, S2, seed=9)
+    gt2, ids2 = T.synthetic_gt(B, S2, C, m=3, seed=5, pad_to=4)
+    tg2 = T.prefetch_targets(C, S2, S2, gt2, ids2)
+    slices = [slice(r * PB, (r + 1) * PB) for r in range(WORLD)]
+    orc = TO.OracleYolo3Train(C, dict(params), device_slices=slices, sync_bn=True)
+    ref_losses = np.stack(orc.forward_train(x2, gt2, *tg2))
+    ref_grads = orc.backward()
+    for r, sl in enumerate(slices):
+        assert bool(ranks[r]["C_replanned"])
+        np.testing.assert_allclose(ranks[r]["C_losses"], ref_losses[:, sl], rtol=1e-4, atol=1e-4)
+        assert len(ranks[r]["C_sync_calls"]) == 12
+        assert ranks[r]["C_buckets"].shape == (4, 2)
+        for key in ranks[r]:
+            if key.startswith("C_grad/"):
+                name = key.split("/", 1)[1]
+                err = np.abs(ranks[r][key] - ref_grads[name]).max() / (np.abs(ref_grads[name]).max() + 1e-6)
+                assert err < 2e-3, (name, err)
+                assert np.array_equal(ranks[0][key], ranks[r][key]), name
+
+
 @pytest.mark.parametrize("extra", [[], ["--mode", "train"], ["--mode", "train", "--syncbn"]])
 def test_bench_starts_its_own_ranks(extra):
-    """`python bench.py --gpus 2` without a rank environment: the parent spawns the ranks itself."""
+    """`python bench.py --gpus 2` without a rank environment: the parent spawns the ranks itself.  In the default
+    mode the line also carries the training legs the driver's scaling run needs: also_train416 (configs[2]) with the
+    forward / backward / exposed-all-reduce split, the all-reduce timed alone and the overlap fraction, and — N > 1 —
+    also_syncbn608 (configs[4]) built through norm_layer=SyncBatchNorm."""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--share-gpu",
-           "--size", "96", "--batch", "2", "--steps", "2", "--warmup", "1", "--cpu-frames", "0"] + extra
+           "--size", "96", "--batch", "2", "--steps", "2", "--warmup", "1", "--cpu-frames", "0",
+           "--train-size", "64", "--train-batch", "2", "--syncbn-size", "96", "--syncbn-batch", "2",
+           "--train-steps", "2"] + extra
     p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
     assert p.returncode == 0, p.stderr.decode()[-2000:]
     lines = [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
@@ -155,3 +192,33 @@ def test_bench_starts_its_own_ranks(extra):
     r = json.loads(lines[0])
     assert r["n_gpus"] == 2 and r["config"]["global_batch"] == 4 and r["value"] > 0
     assert r["scaling"] == "weak" and r["steps"] == 2
+    if not extra:
+        t = r["also_train416"]
+        for k in ("frames_per_s", "ms_per_step", "forward_ms", "backward_ms", "allreduce_exposed_ms", "sgd_ms",
+                  "allreduce_alone_ms", "allreduce_overlap_fraction", "allreduce_busbw_GBps", "traffic"):
+            assert k in t, k
+        assert t["n_gpus"] == 2 and t["global_batch"] == 4 and t["size"] == 64 and t["frames_per_s"] > 0
+        assert t["allreduce_bytes"] >= 61_000_000 * 4 and 0.0 <= t["allreduce_overlap_fraction"] <= 1.0
+        sb = r["also_syncbn608"]
+        assert sb["n_gpus"] == 2 and sb["size"] == 96 and sb["frames_per_s"] > 0
+        assert sb["batchnorm"].startswith("SyncBatchNorm(num_devices=2)")
+        assert "forward_ms" in sb and "allreduce_exposed_ms" in sb
+    else:
+        assert r["roofline"]["forward_ms"] > 0 and "allreduce_exposed_ms" in r["roofline"]
+
+
+def test_default_bench_line_has_the_training_leg_on_one_gpu():
+    """N = 1, default mode (small shapes): also_train416 present with a measured `traffic` when rocprofv3 exists."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--size", "96", "--batch", "2", "--steps", "2", "--warmup", "1",
+           "--cpu-frames", "1", "--train-size", "64", "--train-batch", "2", "--train-steps", "2"]
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1200)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    r = json.loads([l for l in p.stdout.decode().splitlines() if l.startswith("{")][0])
+    t = r["also_train416"]
+    assert t["n_gpus"] == 1 and t["allreduce"].startswith("none") and "also_syncbn608" not in r
+    assert t["forward_ms"] > 0 and t["backward_ms"] > 0 and t["allreduce_exposed_ms"] < 0.5
+    if os.path.exists("/opt/rocm/bin/rocprofv3"):
+        assert r["roofline"]["traffic"] and t["traffic"] and t["traffic"] > 0, (r["roofline"].get("traffic_note"), t.get("traffic_note"))
+    assert r["cpu_baseline"]["kind"] == "port" and r["cpu_baseline_torch"]["kind"] == "independent"
+    assert r["cpu_baseline_torch"]["value"] > 0

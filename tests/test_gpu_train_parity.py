@@ -80,10 +80,12 @@ def test_train_step_matches_oracle(C, B, S):
         assert np.abs(got - params[name]).max() > 0
 
 
-@pytest.mark.parametrize("C,B,H,W", [(5, 2, 64, 128), (3, 1, 160, 96)])
+@pytest.mark.parametrize("C,B,H,W", [(5, 2, 64, 128), (3, 1, 160, 96), (3, 1, 96, 32), (2, 3, 128, 32)])
 def test_train_step_on_rectangular_frames(C, B, H, W):
     """Height != width (multiples of 32): per-axis geometry in the target kernels, the weight-gradient pixel tables,
-    the stride-2 data gradients and the x2-summed transition gradients.  Losses and every gradient against the oracle."""
+    the stride-2 data gradients and the x2-summed transition gradients.  Losses and every gradient against the oracle.
+    The 32-wide shapes are the ones whose BatchNorm-backward partial rows (one per image-row chunk) outnumber the
+    64-pixel chunks the scratch region used to be sized by: an overflow there lands in the weight-gradient slabs."""
     from videoyolo_amd import autograd, init
     from oracle import targets_oracle as T
     from oracle import yolo3_oracle as O

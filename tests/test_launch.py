@@ -27,6 +27,17 @@ class FakeNet:
 net = FakeNet()
 assert parallel.sync_replicas(net) and net._replicas_synced
 assert torch.equal(net._dev_params.view(torch.float32), torch.arange(64, dtype=torch.float32))
+# the recorded forward's resync: only rank 1 wrote parameters since the broadcast — BOTH ranks must enter the
+# broadcast (all-reduce MAX of the dirty flags first), and rank 0's values win again
+FakeNet._device = None
+assert parallel.make_host_group() is not None and parallel.host_group() is not None
+assert not parallel.sync_replicas_if_any_dirty(net)            # nobody dirty: no broadcast anywhere
+if r == 1:
+    net._dev_params.view(torch.float32).mul_(3.0)
+    net._replicas_synced = False
+assert parallel.any_rank(r == 1) and not parallel.any_rank(False)
+assert parallel.sync_replicas_if_any_dirty(net) and net._replicas_synced
+assert torch.equal(net._dev_params.view(torch.float32), torch.arange(64, dtype=torch.float32))
 torch.distributed.barrier()
 print("rank %%d of %%d ok" %% (r, w))
 """

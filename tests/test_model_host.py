@@ -243,3 +243,50 @@ def test_fastdiv_formula_is_exact():
         ns = [0, 1, d - 1, d, d + 1, 2 * d - 1, 2 ** 31 - 1, 2 ** 32 - 1] + [int(v) for v in rng.integers(0, 2 ** 32, 200)]
         for n in ns:
             assert div(n, f) == n // d, (n, d)
+
+
+def test_syncbatchnorm_constructor_argument_is_a_contract(voc_classes):
+    """norm_layer=SyncBatchNorm, norm_kwargs={'num_devices': n} (train_yolov3.py:350-354) is honoured at the first
+    train-mode forward: num_devices must be the number of ranks (one process per GPU); on a single rank it is
+    BatchNorm and says so once; the default BatchNorm needs nothing."""
+    net = _net(voc_classes[:2], norm_layer=vy.SyncBatchNorm, norm_kwargs={"num_devices": 8})
+    with pytest.raises(ValueError, match="num_devices=8"):
+        net._ensure_sync_bn()                      # no process group here: world size 1 != 8
+    with pytest.raises(ValueError):
+        net._ensure_sync_bn()                      # and it keeps raising (not latched by the first attempt)
+    one = _net(voc_classes[:2], norm_layer=vy.SyncBatchNorm, norm_kwargs={"num_devices": 1})
+    with pytest.warns(UserWarning, match="single device"):
+        one._ensure_sync_bn()
+    assert one._sync_hook is None
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        one._ensure_sync_bn()                      # warned once
+        _net(voc_classes[:2])._ensure_sync_bn()    # plain BatchNorm: silent
+
+
+def test_trainer_rejects_options_it_would_otherwise_swallow(voc_classes):
+    net = _net(voc_classes[:2])
+    with pytest.raises(NotImplementedError):
+        vy.Trainer(net.collect_params(), 'sgd', {}, compression_params={"type": "2bit"})
+    with pytest.raises(NotImplementedError):
+        vy.Trainer(net.collect_params(), 'sgd', {}, update_on_kvstore=True)
+    with pytest.raises(ValueError):
+        vy.Trainer(net.collect_params(), 'sgd', {"clip_gradient": 1.0})
+    vy.Trainer(net.collect_params(), 'sgd', {'wd': 5e-4, 'momentum': 0.9}, kvstore='local')   # train_yolov3.py:527-530
+
+
+def test_record_nested_in_train_mode_is_an_outermost_recording():
+    """autograd.record() inside train_mode() / pause() still starts a fresh tape (only record scopes nest)."""
+    s = autograd._get()
+    with autograd.train_mode():
+        with autograd.record():
+            s.tape.append("stale")
+    with autograd.train_mode():
+        with autograd.pause():
+            with autograd.record():
+                assert s.tape == []
+                with autograd.record():
+                    s.tape.append("inner")
+                assert s.tape == ["inner"]           # a nested record() does not clear
+    assert not autograd.is_recording() and not autograd.is_training()

@@ -2,7 +2,7 @@
 for the last steps, reports: the union of kernel intervals (device busy), the time no kernel runs (launch gaps and
 dependencies), and per kernel family the exclusive time (alone on the device) vs time shared with another queue.
 
-    rocprofv3 --kernel-trace --output-format csv -d gpurun_out/tl -- python3 bench.py --mode train --steps 6 --warmup 2
+    rocprofv3 --kernel-trace --output-format csv -d gpurun_out/tl -- python3 bench.py --mode train --steps 6 --warmup 2 --no-pmc
     python tools/step_timeline.py gpurun_out/tl
 """
 import csv

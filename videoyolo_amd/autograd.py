@@ -27,10 +27,12 @@ def is_training():
 def _scope(recording, training):
     s = _get()
     prev = (s.recording, s.training)
-    depth = getattr(s, "depth", 0)
-    if recording and depth == 0:
-        s.tape = []  # an outermost record(): forwards recorded earlier and never back-propagated are dropped
-    s.depth = depth + 1
+    # only record() scopes count: a record() nested in train_mode() / pause() is still an outermost recording
+    rec_depth = getattr(s, "rec_depth", 0)
+    if recording:
+        if rec_depth == 0:
+            s.tape = []  # an outermost record(): forwards recorded earlier and never back-propagated are dropped
+        s.rec_depth = rec_depth + 1
     if recording is not None:
         s.recording = recording
     if training is not None:
@@ -39,7 +41,7 @@ def _scope(recording, training):
         yield
     finally:
         s.recording, s.training = prev
-        s.depth = depth
+        s.rec_depth = rec_depth
 
 
 def record(train_mode=True):

@@ -166,6 +166,9 @@ hipError_t vy_launch_stem(const StemArgs& a, hipStream_t s) {
 // training: raw conv -> z plane + partials[vy_stem_blocks][2][32] (double)
 hipError_t vy_launch_stem_raw(const StemArgs& a, double* partials, hipStream_t s) {
   if (stem_check(a) != hipSuccess) return hipErrorInvalidValue;
+  // RAW mode folds every computed pixel into the BatchNorm partial sums: a partial last 32-pixel tile (whose
+  // columns past W come from uninitialised LDS and are only dropped by the store descriptor) would poison them
+  if (a.W % 32 != 0) return hipErrorInvalidValue;
   const int rows = stem_rows(a.W);
   const size_t lds = (size_t)3 * (rows + 2) * (((a.W + 31) & ~31) + 8) * sizeof(float);
   if (lds > 48 * 1024) {

@@ -153,6 +153,13 @@ size_t train_plan(vy_net* net, int b, int h, int w, bool commit) {
       size_t pf = 2 * (c.is_stem ? (size_t)vy_stem_blocks(b, h, w) * 64 : tiles_m * 2 * c.cout);  // doubles
       const size_t chunks = (size_t)((M + kBwdChunk - 1) / kBwdChunk);
       if (chunks * 2 * c.cout > pf) pf = chunks * 2 * c.cout;
+      // bn_bwd_reduce chunks by image rows, not by 64 pixels: ceil(B*Ho / rows_per_chunk) partial rows of 2*C
+      // floats — more than the pixel-chunk bound on maps narrower than 64 pixels (W = 32 training shapes)
+      {
+        const int rpc = vy_bn_bwd_rows_per_chunk(b, Ho, c.cout);
+        const size_t bwd_rows = (size_t)(((long long)b * Ho + rpc - 1) / rpc);
+        if (bwd_rows * 2 * c.cout > pf) pf = bwd_rows * 2 * c.cout;
+      }
       if (c.is_stem) {
         const size_t sw = (size_t)vy_stem_wgrad_blocks(b, h, w) * 864;
         if (sw > pf) pf = sw;

@@ -35,7 +35,12 @@ class BatchNorm:
 
 
 class SyncBatchNorm:
-    """Marker for ``norm_layer=gluon.contrib.nn.SyncBatchNorm`` (train_yolov3.py:352)."""
+    """``norm_layer=gluon.contrib.nn.SyncBatchNorm`` with ``norm_kwargs={'num_devices': n}`` (train_yolov3.py:350-354).
+    Passing this class to ``yolo3_darknet53`` makes the layers that receive ``norm_layer`` in the reference — the stem
+    and the five stride-2 convs of the backbone (three_darknet.py:163-181; the residual blocks hard-code BatchNorm,
+    darknet.py:89-91, and wrappers.py:101-103 does not forward it to the heads) — normalise with the statistics of
+    the GLOBAL batch: their [2][C] sums are all-reduced over the process group, forward and backward.  With one
+    process per GPU ``num_devices`` must equal the world size (``YOLOV3._ensure_sync_bn``)."""
 
 
 class Parameter:
@@ -136,6 +141,8 @@ class YOLOV3(object):
         self._mom = None         # torch float32 flat SGD momentum buffer
         self._train_x = None     # image batch of the recorded forward (stem weight gradient)
         self._cb_keep = []       # ctypes callbacks kept alive
+        self._sync_hook = None   # parallel.SyncBatchNormHook once installed (norm_layer=SyncBatchNorm or by hand)
+        self._sync_bn_checked = False
         self._replicas_synced = False  # parameters broadcast from rank 0 since they were last written (parallel.sync_replicas)
         self._opts_sent = {}     # index -> (lr_mult, wd_mult, enabled) as last handed to the library
         self._device = None
@@ -442,6 +449,7 @@ class YOLOV3(object):
         self._host, self._dev_params, self._ws, self._plan, self._device = {}, None, None, None, None
         self._grads = self._mom = None
         self._opts_sent = {}
+        self._sync_hook, self._sync_bn_checked = None, False  # the new library handle has no callback yet
         for k, v in new_vals.items():
             self._params[k].set_data(v)
         if device is not None:
@@ -534,11 +542,15 @@ class YOLOV3(object):
         b, _, h, w = x.shape
         tg = [self._dev(t) for t in (gt_boxes, obj_t, centers_t, scales_t, weights_t, clas_t)]
         m = int(tg[0].shape[1])
-        if not self._replicas_synced:
-            from . import parallel
-            parallel.sync_replicas(self)  # data parallel: all ranks train the same model (no-op single process)
+        from . import parallel
+        # data parallel: all ranks train the same model.  Collective-safe: the ranks first agree (all-reduce MAX of
+        # their dirty flags) whether anybody wrote parameters since the last broadcast (no-op single process).
+        parallel.sync_replicas_if_any_dirty(self)
         with torch.cuda.device(self._device):
             self._ensure_plan(b, h, w, train=True)
+            self._ensure_sync_bn()
+            if self._sync_hook is not None:
+                self._sync_hook.begin_step()
             n = self._lib.vy_net_num_anchors(self._h)
             c = len(self._classes)
             want = [(b, m, 4), (b, n, 1), (b, n, 2), (b, n, 2), (b, n, 2), (b, n, c)]
@@ -555,6 +567,31 @@ class YOLOV3(object):
         self._train_x = x
         autograd._register(self)
         return tuple(autograd.loss_vector(losses[i], self, i) for i in range(4))
+
+    def _ensure_sync_bn(self):
+        """Honour ``norm_layer=SyncBatchNorm, norm_kwargs={'num_devices': n}`` (train_yolov3.py:350-354) at the first
+        train-mode forward: with more than one rank install the statistics all-reduce
+        (parallel.SyncBatchNormHook); ``num_devices`` must be the number of ranks — one process drives one GPU here,
+        where the reference's single process drives ``len(ctx)``.  One rank: SyncBatchNorm over one device IS
+        BatchNorm; warn once.  Plain ``BatchNorm`` (the default): nothing to do."""
+        if self._sync_bn_checked:
+            return
+        self._sync_bn_checked = True
+        if self._norm_layer is not SyncBatchNorm and not (
+                isinstance(self._norm_layer, type) and self._norm_layer.__name__ == "SyncBatchNorm"):
+            return
+        from . import parallel
+        world = parallel.world_size()
+        nd = (self._norm_kwargs or {}).get("num_devices")
+        if nd is not None and int(nd) != world:
+            self._sync_bn_checked = False
+            raise ValueError("norm_layer=SyncBatchNorm with num_devices=%s, but the process group has %d rank(s): one "
+                             "process drives one GPU (start N ranks: torchrun / videoyolo_amd.launch)" % (nd, world))
+        if world == 1:
+            warnings.warn("norm_layer=SyncBatchNorm on a single device: identical to BatchNorm, no statistics exchange")
+            return
+        if self._sync_hook is None:
+            parallel.SyncBatchNormHook(self)
 
     def backward(self):
         """autograd.backward(sum of the four losses) for this net (train_yolov3.py:631)."""
@@ -586,6 +623,7 @@ class YOLOV3(object):
             fms.append(np.zeros((1, 1, hh, ww), np.float32))
         with torch.cuda.device(self._device):
             self._ensure_plan(b, h, w, train=True)
+            self._ensure_sync_bn()
             n = self._lib.vy_net_num_anchors(self._h)
             c = len(self._classes)
             outs = [torch.empty((b, n, k), dtype=torch.float32, device=self._device) for k in (4, 2, 2, 1, c)]

@@ -79,20 +79,75 @@ def broadcast_(tensor, src=0):
     return tensor
 
 
+_host_group = None
+
+
+def host_group():
+    """A process group whose collectives run on HOST tensors (gloo), for control-plane agreement that must not
+    synchronise the GPU stream: the default group if it is gloo, else a gloo group created beside the RCCL one.
+    Creating it is collective — ``Trainer.__init__`` (which every rank runs) does it; returns None before that."""
+    return _host_group
+
+
+def make_host_group():
+    """Collective: every rank must call it (idempotent)."""
+    global _host_group
+    if not is_initialized() or world_size() == 1 or _host_group is not None:
+        return _host_group
+    dist = _dist()
+    if dist.get_backend() == "gloo":
+        _host_group = dist.group.WORLD
+    else:
+        _host_group = dist.new_group(backend="gloo")
+    return _host_group
+
+
+def any_rank(flag, device=None):
+    """True on every rank iff `flag` is true on at least one: all-reduce(MAX) of one integer.  Every rank must
+    call it.  Runs on the host group when there is one (no GPU synchronisation); otherwise on a device tensor of
+    the default group (one small RCCL all-reduce and a host read-back)."""
+    if not is_initialized() or world_size() == 1:
+        return bool(flag)
+    import torch
+    dist = _dist()
+    if _host_group is not None:
+        t = torch.tensor([1 if flag else 0], dtype=torch.int32)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=_host_group)
+        return bool(t.item())
+    t = torch.tensor([1 if flag else 0], dtype=torch.int32,
+                     device=device if dist.get_backend() != "gloo" else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return bool(t.item())
+
+
 def sync_replicas(net, src=0):
     """Make every rank's replica identical to rank `src`'s: one broadcast of the flat device parameter
     buffer (weights, gamma/beta, running statistics) — what ``Trainer(kvstore='local')`` gives the
     reference for free, because there ONE initialised copy is pushed to all devices
     (train_yolov3.py:428,494,527-530).  With one process per GPU each rank runs its own
-    ``net.initialize()``, and an unseeded one draws different weights on every rank.  Called by
-    ``Trainer.__init__`` and (lazily, whenever parameters were written since the last sync) by the
-    recorded forward; collective — every rank must reach it."""
+    ``net.initialize()``, and an unseeded one draws different weights on every rank.  Collective — every
+    rank must reach it: ``Trainer.__init__`` calls it unconditionally; the recorded forward calls
+    ``sync_replicas_if_any_dirty`` (below), which first AGREES across ranks on whether anybody wrote parameters."""
     import torch
     if not is_initialized() or world_size() == 1 or net._dev_params is None:
         return False
     broadcast_(net._dev_params.view(torch.float32), src)
     net._replicas_synced = True
     return True
+
+
+def sync_replicas_if_any_dirty(net, src=0):
+    """Recorded-forward hook: re-broadcast rank `src`'s parameters iff ANY rank wrote parameters since the last
+    broadcast (``if rank == 0: net.load_parameters(...)`` after the Trainer exists is legal in the reference,
+    where one process owns all devices).  The decision is an all-reduce(MAX) of the per-rank dirty flags, so all
+    ranks take the same branch: a rank-local flag alone would send only the writing ranks into the broadcast and
+    hang the others in their next collective."""
+    if not is_initialized() or world_size() == 1 or net._dev_params is None:
+        return False
+    make_host_group()  # first call on every rank = their first recorded forward (or Trainer()): collective, then cached
+    if any_rank(not net._replicas_synced, net._device):
+        return sync_replicas(net, src)
+    return False
 
 
 def gather_detections(ids, scores, bboxes):
@@ -115,18 +170,24 @@ def gather_detections(ids, scores, bboxes):
 
 class SyncBatchNormHook(object):
     """Installs the statistics all-reduce for SyncBatchNorm(num_devices) (train_yolov3.py:352-354):
-    the library calls back with a device pointer into the net's workspace and a count of doubles."""
+    the library calls back with a device pointer into the net's workspace and a count of doubles.
+    ``yolo3_darknet53(..., norm_layer=SyncBatchNorm, norm_kwargs={'num_devices': n})`` installs it by itself at
+    the first recorded forward (model.YOLOV3._ensure_sync_bn); it survives re-planning (multi-scale training,
+    train_yolov3.py:258-271): the workspace tensor is looked up per call, the callback registration lives in the
+    library's per-net training state."""
 
     def __init__(self, net):
         import torch
         from . import _lib
         self.net = net
-        self.calls = []   # doubles per statistics exchange, in call order (6 layers forward + 6 backward per step)
+        self.calls = []   # doubles per statistics exchange of the CURRENT step, in call order (6 fwd + 6 bwd)
 
         def cb(user, ptr, count):
             try:
                 ws = net._ws
                 off = int(ptr) - ws.data_ptr()
+                if off < 0 or off + 8 * count > ws.numel():
+                    raise RuntimeError("SyncBatchNorm statistics pointer outside the bound workspace")
                 view = ws[off:off + 8 * count].view(torch.float64)
                 _dist().all_reduce(view)
                 self.calls.append(int(count))
@@ -137,7 +198,12 @@ class SyncBatchNormHook(object):
                 return 1
         self._cb = _lib.ALLREDUCE_CB(cb)
         net._cb_keep.append(self._cb)
+        net._sync_hook = self
         _lib.check(net._lib.vy_net_set_sync_bn(net._h, world_size(), self._cb, None))
+
+    def begin_step(self):
+        """Called by the recorded forward: the call log covers one step (it is instrumentation, not state)."""
+        self.calls = []
 
 
 class GradBucketOverlap(object):
@@ -151,7 +217,8 @@ class GradBucketOverlap(object):
         self.net = net
         self.stream = torch.cuda.Stream(device=net._device) if net._device is not None else None
         self.pending = []
-        self.launched = []   # (element offset, element count) of every bucket handed to the all-reduce
+        self.launched = []       # (element offset, element count) of the buckets handed out since the last finish()
+        self.last_launched = []  # the same for the step that finish() closed last (instrumentation)
 
         def cb(user, off, count):
             try:
@@ -184,5 +251,7 @@ class GradBucketOverlap(object):
         for w in self.pending:
             w.wait()
         self.pending = []
+        if self.launched:
+            self.last_launched, self.launched = self.launched, []
         if self.stream is not None:
             torch.cuda.current_stream(self.net._device).wait_stream(self.stream)

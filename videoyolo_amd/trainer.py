@@ -26,8 +26,16 @@ class Trainer(object):
         self._num_update = 0
         self._kvstore = kvstore
         self._overlap = None
+        if compression_params is not None:
+            raise NotImplementedError("gradient compression (compression_params) is not on the reference's path "
+                                      "(train_yolov3.py:527-530 passes none)")
+        if update_on_kvstore:
+            raise NotImplementedError("update_on_kvstore=True: every rank applies the update itself after the "
+                                      "all-reduce (the reference's kvstore='local' resolves to the same)")
         # kvstore init: every device starts from the same parameters (rank 0's); if the parameters are not
-        # on the device yet the recorded forward does it (model.forward_train)
+        # on the device yet the recorded forward does it (model.forward_train).  Every rank constructs its
+        # Trainer, so this is also where the host-side (gloo) control group is created.
+        parallel.make_host_group()
         parallel.sync_replicas(self._net)
 
     @property
