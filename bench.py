@@ -599,6 +599,9 @@ def bench_train(args, vy, dev, dist, rank, world, traffic=None, traffic_note=Non
                    "per_gpu_batch": args.batch, "global_batch": leg["global_batch"], "size": args.size,
                    "classes": args.classes, "parallelism": "dp%d" % world, "loss_rank0": leg["loss_rank0"]},
     }
+    if "forward_ms" in leg:
+        result["step_split"] = {k: leg[k] for k in ("forward_ms", "backward_ms", "allreduce_exposed_ms", "sgd_ms",
+                                                     "allreduce_alone_ms", "allreduce_overlap_fraction") if k in leg}
     if "forward_ms" in leg and "frac_forward_backward" in leg:
         fw, bw = leg["forward_ms"], leg["backward_ms"]
         result["roofline"] = {

@@ -204,7 +204,7 @@ def test_bench_starts_its_own_ranks(extra):
         assert sb["batchnorm"].startswith("SyncBatchNorm(num_devices=2)")
         assert "forward_ms" in sb and "allreduce_exposed_ms" in sb
     else:
-        assert r["roofline"]["forward_ms"] > 0 and "allreduce_exposed_ms" in r["roofline"]
+        assert r["step_split"]["forward_ms"] > 0 and "allreduce_exposed_ms" in r["step_split"]   # (roofline: 416 / 608 only)
 
 
 def test_default_bench_line_has_the_training_leg_on_one_gpu():
