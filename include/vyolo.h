@@ -74,7 +74,8 @@ void vy_net_destroy(vy_net* net);
  *   nms_topk <= 0                  "-1 to disable": EVERY valid candidate goes through NMS (consumed in
  *                                  score order in chunks of VY_MAX_TOPK until post_nms rows are kept); needs
  *                                  post_nms in [1, VY_MAX_TOPK] — the un-sliced result would have N*C rows
- *   nms_topk > VY_MAX_TOPK         rejected by the forward (VY_ERR_UNSUPPORTED)
+ *   nms_topk > VY_MAX_TOPK         the same chunked kernel, stopped after nms_topk candidates; also needs
+ *                                  post_nms in [1, VY_MAX_TOPK] (otherwise VY_ERR_UNSUPPORTED from the forward)
  *   post_nms <= 0                  the outputs have nms_topk rows (no slice, yolo3.py:1201-1202)
  *   nms_thresh outside (0, 1)      no NMS at all: see vy_net_forward_infer */
 #define VY_MAX_TOPK 1024
@@ -106,6 +107,14 @@ size_t vy_net_workspace_bytes(const vy_net* net, int32_t batch, int32_t height, 
 int vy_net_bind_workspace(vy_net* net, void* dev_ws, size_t bytes, int32_t batch, int32_t height,
                           int32_t width, void* stream);
 
+/* Inference activation planes are recycled by liveness (a residual stage needs two alternating block-output planes
+ * and one bottleneck plane, not two per block: 608x608 batch 64 plans ~3x less workspace) — the intermediate
+ * activations of a finished forward are then gone, like the intermediates of the reference's hybridized graph.
+ * keep != 0 gives every cell its own plane so that vy_net_read_activation works (parity taps).  Changes the plan:
+ * call before vy_net_workspace_bytes / vy_net_bind_workspace (a bound workspace is unbound by a change).  Training
+ * plans always keep every plane (backward reads them). */
+int vy_net_set_keep_activations(vy_net* net, int32_t keep);
+
 /* Number of anchors N = 3 * sum_i (H/s_i)(W/s_i) for the planned shape. */
 int32_t vy_net_num_anchors(const vy_net* net);
 
@@ -128,7 +137,8 @@ int vy_net_forward_infer(vy_net* net, const float* x, float* ids, float* scores,
  * NCHW — i = 0,1,2 for strides 32,16,8. */
 int vy_net_read_head(vy_net* net, int32_t i, float* dst_dev, void* stream);
 /* copy the activation of feature cell `name` ("stages.0.14", "yolo_blocks.1.tip", ...) to dst
- * as NCHW; returns its channel count / height / width through the out pointers. */
+ * as NCHW; returns its channel count / height / width through the out pointers.  With dst != NULL it needs a plan
+ * that keeps every plane (vy_net_set_keep_activations, or a training plan): VY_ERR_STATE otherwise. */
 int vy_net_read_activation(vy_net* net, const char* name, float* dst_dev, int32_t* c, int32_t* h,
                            int32_t* w, void* stream);
 

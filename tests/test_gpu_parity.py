@@ -48,6 +48,7 @@ def test_intermediate_cells(voc_classes, synth20, name):
     from oracle import yolo3_oracle as O
     x = frames(2, 64, seed=7)
     net = _net(voc_classes, synth20)
+    net.keep_activations()        # inference planes are recycled by default: taps need every cell's own plane
     net(x)
     orc = _oracle(synth20)
     taps = {}
@@ -403,9 +404,35 @@ def test_nms_topk_disabled_uses_every_valid_candidate(voc_classes, size, post, o
     net.set_nms(0.45, -1, -1)
     with pytest.raises(_lib.VyError):
         net(x)
-    net.set_nms(0.45, 2000, 100)
+    net.set_nms(0.45, 2000, -1)                       # nms_topk > 1024 without a slice: 2000 output rows
     with pytest.raises(_lib.VyError):
         net(x)
+
+
+@pytest.mark.parametrize("topk,post", [(1025, 100), (2000, 400), (3000, 1024), (5000, 60)])
+def test_nms_topk_above_one_chunk(voc_classes, topk, post):
+    """set_nms(nms_topk > 1024) (yolo3.py:1208-1228 accepts any): the topk best valid candidates are consumed in
+    1024-entry chunks (the last one shortened to the cap).  Kept rows exact against the oracle's box_nms(topk)."""
+    from videoyolo_amd import init
+    from oracle import yolo3_oracle as O
+    params = init.synthetic_params(O.param_shapes(20), seed=233)
+    x = frames(2, 128, seed=topk)
+    net = _net(voc_classes, params)
+    net.set_nms(0.45, topk, post)
+    ids, scores, bboxes, keep = [t.cpu().numpy() for t in net(x, return_index=True)]
+    r = _oracle(params, nms_topk=topk, post_nms=post)(x)
+    assert ids.shape == (2, post, 1)
+    assert np.array_equal(keep, r[3]) and np.array_equal(ids, r[0])
+    np.testing.assert_allclose(scores, r[1], rtol=0, atol=TOL)
+    fin = np.isfinite(r[2])
+    np.testing.assert_allclose(bboxes[fin], r[2][fin], rtol=0, atol=TOL)
+    # the cap is honoured: every kept row is one of the topk best-scored valid candidates of its image
+    det = _oracle(params).detections(x)
+    for b in range(2):
+        sc = det[b, :, 1]
+        order = np.argsort(-sc, kind="stable")
+        best = set(order[:topk][sc[order[:topk]] > 0.01].tolist())
+        assert set(keep[b][keep[b] >= 0].tolist()) <= best
 
 
 def test_denormal_range_is_kept():
@@ -422,6 +449,7 @@ def test_denormal_range_is_kept():
     params["stages.0.0.1.running_var"][:] = 1
     x = (np.random.default_rng(0).standard_normal((1, 3, 64, 64)) * 1e-9).astype(np.float32)
     net = _net(classes, params)
+    net.keep_activations()
     net(x)
     orc = _oracle(params, 3)
     taps = {}
@@ -438,3 +466,31 @@ def test_denormal_range_is_kept():
     sub = (np.abs(want) < np.finfo(np.float32).tiny) & (want != 0)
     assert sub.sum() > 1000, "the case must actually exercise subnormals"
     assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("size,batch", [(96, 3), (75, 2), (416, 1)])
+def test_recycled_planes_change_nothing_but_the_workspace(voc_classes, synth20, size, batch):
+    """Default inference plan (planes recycled by liveness) vs vy_net_set_keep_activations(1): identical heads and
+    detections bit for bit, a workspace of little more than half the size, and read_activation refused in the recycled plan."""
+    import torch
+    from videoyolo_amd import _lib
+    x = frames(batch, size, seed=size)
+    lean = _net(voc_classes, synth20)
+    a = [t.clone() for t in lean(x, return_index=True)]
+    ha = [lean.read_head(i).clone() for i in range(3)]
+    keep = _net(voc_classes, synth20)
+    keep.keep_activations()
+    b = keep(x, return_index=True)
+    hb = [keep.read_head(i) for i in range(3)]
+    assert all(torch.equal(p, q) for p, q in zip(a, b)) and all(torch.equal(p, q) for p, q in zip(ha, hb))
+    assert lean._ws.numel() < 0.6 * keep._ws.numel(), (lean._ws.numel(), keep._ws.numel())
+    with pytest.raises(_lib.VyError, match="recycled"):
+        lean.read_activation("stages.0.2.body.1")
+    keep.read_activation("stages.0.2.body.1")
+    # a second forward on the recycled plan (stale interiors from the first one) and a switch of mode on the same object
+    a2 = lean(x, return_index=True)
+    assert all(torch.equal(p, q) for p, q in zip(a, a2))
+    lean.keep_activations()
+    a3 = lean(x, return_index=True)
+    assert all(torch.equal(p, q) for p, q in zip(a, a3))
+    lean.read_activation("yolo_blocks.1.tip")

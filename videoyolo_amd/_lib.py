@@ -45,6 +45,7 @@ SIGNATURES = {
     "vy_net_param_get": (ctypes.c_int, [_vp, _i32, _vp, _vp]),
     "vy_net_workspace_bytes": (_sz, [_vp, _i32, _i32, _i32]),
     "vy_net_bind_workspace": (ctypes.c_int, [_vp, _vp, _sz, _i32, _i32, _i32, _vp]),
+    "vy_net_set_keep_activations": (ctypes.c_int, [_vp, _i32]),
     "vy_net_num_anchors": (_i32, [_vp]),
     "vy_net_forward_infer": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "vy_net_read_head": (ctypes.c_int, [_vp, _i32, _vp, _vp]),

@@ -622,8 +622,11 @@ __global__ __launch_bounds__(kNmsThreads) void sort_nms_kernel(const DetArgs d, 
 // worst case (everything suppressed) walks all N*C candidates, like the reference's unbounded O(n^2) loop.
 constexpr int kAllThreads = 1024;
 
+// The same loop serves nms_topk > VY_NMS_MAX_TOPK (`topk_cap` > 0): box_nms keeps the topk best valid candidates and
+// suppresses among those, so the chunks stop once topk_cap candidates have been consumed (the last chunk is
+// shortened to what is left of the cap).
 __global__ __launch_bounds__(kAllThreads) void nms_all_kernel(const DetArgs d, void* scratch, int n_items, int rows,
-                                                              float* ids, float* scores, float* bboxes,
+                                                              int topk_cap, float* ids, float* scores, float* bboxes,
                                                               int32_t* keep_idx) {
   const int b = blockIdx.x, t = threadIdx.x;
   Scratch sc = carve(scratch, d.B);
@@ -654,8 +657,10 @@ __global__ __launch_bounds__(kAllThreads) void nms_all_kernel(const DetArgs d, v
   // exclusive upper bound on the key of the candidates still to be consumed (none yet)
   uint32_t bound_s = 0xffffffffu, bound_i = 0xffffffffu;
   bool first = true;
+  int consumed = 0;  // candidates taken by earlier chunks (uniform)
   __syncthreads();
   while (true) {
+    const int k_limit = (topk_cap > 0 && topk_cap - consumed < VY_NMS_MAX_TOPK) ? topk_cap - consumed : VY_NMS_MAX_TOPK;
     if (t == 0) {
       st.Tb = st.Ts = st.smask = st.Ti = st.imask = 0;
       st.k_rem = st.k_eff = st.done = st.count = 0;
@@ -690,7 +695,7 @@ __global__ __launch_bounds__(kAllThreads) void nms_all_kernel(const DetArgs d, v
       }
       if (t == 0 && pass == 0) {
         const int nvalid = pos[0];
-        st.k_eff = nvalid < VY_NMS_MAX_TOPK ? nvalid : VY_NMS_MAX_TOPK;
+        st.k_eff = nvalid < k_limit ? nvalid : k_limit;
         st.k_rem = st.k_eff;
         if (st.k_eff == 0) st.done = 1;
       }
@@ -819,7 +824,9 @@ __global__ __launch_bounds__(kAllThreads) void nms_all_kernel(const DetArgs d, v
     __syncthreads();
     if (t == 0) n_kept = (nk + add < rows) ? nk + add : rows;
     __syncthreads();
-    if (n_kept >= rows || k < VY_NMS_MAX_TOPK) break;  // enough rows, or the candidates are exhausted
+    consumed += k;
+    // enough rows, or the candidates are exhausted, or the topk best have all been through
+    if (n_kept >= rows || k < k_limit || (topk_cap > 0 && consumed >= topk_cap)) break;
     bound_s = (uint32_t)(last >> 32);
     bound_i = (uint32_t)(last & 0xffffffffull);
     first = false;
@@ -881,8 +888,10 @@ size_t vy_det_scratch_bytes(int B, int n_items, int C) {
 
 hipError_t vy_launch_detect(const DetArgs& a, void* scratch, float* ids, float* scores, float* bboxes,
                             int32_t* keep_idx, hipStream_t s) {
-  if (a.topk > VY_NMS_MAX_TOPK || a.n_cand >= (1 << kIdxBits)) return hipErrorInvalidValue;
-  if (a.topk <= 0 && (a.post_nms <= 0 || a.post_nms > VY_NMS_MAX_TOPK)) return hipErrorInvalidValue;
+  if (a.n_cand >= (1 << kIdxBits)) return hipErrorInvalidValue;
+  // nms_topk <= 0 or > VY_NMS_MAX_TOPK: the chunked kernel, whose kept-row arrays hold post_nms <= VY_NMS_MAX_TOPK rows
+  const bool chunked = a.topk <= 0 || a.topk > VY_NMS_MAX_TOPK;
+  if (chunked && (a.post_nms <= 0 || a.post_nms > VY_NMS_MAX_TOPK)) return hipErrorInvalidValue;
   const int rows = a.post_nms > 0 ? a.post_nms : a.topk;
   // state + histogram region back to zero (entries need no clearing)
   hipError_t e = hipMemsetAsync(scratch, 0,
@@ -900,10 +909,10 @@ hipError_t vy_launch_detect(const DetArgs& a, void* scratch, float* ids, float* 
     if (a.head[i].cs > kTileFloats || (a.head[i].cs & 3) || (a.head[i].co & 3)) return hipErrorInvalidValue;
   }
   const dim3 hgrid(hblocks, a.B);
-  if (a.topk <= 0) {  // every valid candidate goes through NMS: pass 0 only fills the score cache
+  if (chunked) {  // every valid candidate (or the topk > 1024 best) goes through NMS: pass 0 only fills the score cache
     hipLaunchKernelGGL(hist_kernel, hgrid, dim3(kHistThreads), 0, s, a, scratch, 0, n_items);
-    hipLaunchKernelGGL(nms_all_kernel, dim3(a.B), dim3(kAllThreads), 0, s, a, scratch, n_items, rows, ids, scores,
-                       bboxes, keep_idx);
+    hipLaunchKernelGGL(nms_all_kernel, dim3(a.B), dim3(kAllThreads), 0, s, a, scratch, n_items, rows,
+                       a.topk > 0 ? a.topk : 0, ids, scores, bboxes, keep_idx);
     return hipGetLastError();
   }
   hipLaunchKernelGGL(hist_kernel, hgrid, dim3(kHistThreads), 0, s, a, scratch, 0, n_items);

@@ -129,20 +129,30 @@ static int check_shape(int32_t batch, int32_t h, int32_t w) {
 
 size_t vy_net_workspace_bytes(const vy_net* net, int32_t batch, int32_t height, int32_t width) {
   if (!net || check_shape(batch, height, width)) return 0;
-  return const_cast<vy_net*>(net)->plan(batch, height, width, false);
+  return const_cast<vy_net*>(net)->plan(batch, height, width, false, net->keep_activations);
 }
 
 int vy_net_bind_workspace(vy_net* net, void* dev_ws, size_t bytes, int32_t batch, int32_t height, int32_t width,
                           void* stream) {
   if (!net || !dev_ws) return fail(VY_ERR_INVALID, "null argument");
   if (int rc = check_shape(batch, height, width)) return rc;
-  const size_t need = net->plan(batch, height, width, false);
+  const size_t need = net->plan(batch, height, width, false, net->keep_activations);
   if (bytes < need) return fail(VY_ERR_INVALID, "workspace too small: %zu < %zu bytes", bytes, need);
-  net->plan(batch, height, width, true);
+  net->plan(batch, height, width, true, net->keep_activations);
   net->dev_ws = static_cast<unsigned char*>(dev_ws);
   net->ws_bytes = bytes;
   net->fold_uploaded = false;
   HIP_TRY(hipMemsetAsync(dev_ws, 0, need, static_cast<hipStream_t>(stream)));
+  return 0;
+}
+
+int vy_net_set_keep_activations(vy_net* net, int32_t keep) {
+  if (!net) return fail(VY_ERR_INVALID, "net is null");
+  if ((keep != 0) != net->keep_activations) {
+    net->keep_activations = keep != 0;
+    net->dev_ws = nullptr;  // the plan changed: the workspace has to be sized and bound again
+    net->ws_bytes = 0;
+  }
   return 0;
 }
 
@@ -173,6 +183,9 @@ int vy_net_read_activation(vy_net* net, const char* name, float* dst_dev, int32_
                            void* stream) {
   if (!net || !name) return fail(VY_ERR_INVALID, "bad argument");
   if (int rc = net->check_ready()) return rc;
+  if (dst_dev && net->planes_shared)
+    return fail(VY_ERR_STATE, "activation planes are recycled in this plan: call vy_net_set_keep_activations(net, 1) "
+                "before sizing / binding the workspace to read intermediate activations");
   for (const ConvT& cv : net->convs) {
     if (cv.name != name) continue;
     const PlaneT& p = net->planes[cv.out_plane];

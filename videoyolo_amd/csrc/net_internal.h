@@ -6,6 +6,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <algorithm>
 #include <string>
 #include <utility>
 #include <vector>
@@ -71,6 +72,8 @@ struct vy_net {
   int B = 0, H = 0, W = 0;
   size_t fold_desc_off = 0, det_scratch_off = 0, planes_off = 0;  // byte offsets in workspace
   bool fold_uploaded = false;
+  bool keep_activations = false;  // vy_net_set_keep_activations: inference planes are not recycled (parity taps)
+  bool planes_shared = false;     // the committed plan recycles planes (read_activation is then meaningless)
   struct VyTrain* train = nullptr;  // training planner state, owned by train.hip
 
   int add_param(const std::string& name, int kind, int ndim, const int* shape, int trainable, int backbone) {
@@ -241,7 +244,49 @@ struct vy_net {
   // ---- planning
   static size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
 
-  size_t plan(int b, int h, int w, bool commit) {
+  // Plane -> storage slot.  keep_all (training, or vy_net_set_keep_activations): every plane has its own storage — the
+  // backward pass (and the parity taps) read them all.  Otherwise planes are recycled by liveness: a plane may take over
+  // the storage of an earlier plane of the SAME geometry (channel stride and resolution: the zero borders coincide and
+  // stay zero, the interior is fully overwritten by the producing conv) once every reader of that plane has been
+  // launched — strictly before the new plane's first writer, because a conv reads its input / addend while it writes.
+  // In a residual stage that is two alternating block-output planes and one bottleneck plane instead of 2 x blocks.
+  std::vector<int> plane_slots(bool keep_all) const {
+    const int np = (int)planes.size();
+    std::vector<int> slot(np);
+    for (int i = 0; i < np; ++i) slot[i] = i;
+    if (keep_all) return slot;
+    const int kLive = 1 << 30;
+    std::vector<int> def(np, kLive), last(np, -1);
+    for (int ci = 0; ci < (int)convs.size(); ++ci) {
+      const ConvT& c = convs[ci];
+      if (c.out_plane >= 0 && ci < def[c.out_plane]) def[c.out_plane] = ci;
+      if (c.in_plane >= 0 && ci > last[c.in_plane]) last[c.in_plane] = ci;
+      if (c.res_plane >= 0 && ci > last[c.res_plane]) last[c.res_plane] = ci;
+    }
+    for (int i = 0; i < 3; ++i) last[head_plane[i]] = kLive;  // read by decode + NMS (and vy_net_read_head) afterwards
+    std::vector<int> order(np);
+    for (int i = 0; i < np; ++i) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return def[a] < def[b]; });
+    std::vector<int> free_at(np, -1);  // per slot (= index of the plane that owns the storage): last reader so far
+    std::vector<int> owners;
+    for (int p : order) {
+      int take = -1;
+      for (int o : owners)
+        if (planes[o].C == planes[p].C && planes[o].div == planes[p].div && free_at[o] < def[p]) {
+          take = o;
+          break;
+        }
+      if (take < 0) {
+        take = p;
+        owners.push_back(p);
+      }
+      slot[p] = take;
+      free_at[take] = last[p];
+    }
+    return slot;
+  }
+
+  size_t plan(int b, int h, int w, bool commit, bool keep_all) {
     size_t off = 0;
     const size_t fold_off = off;
     off += al(sizeof(FoldDesc) * folds.size());
@@ -255,17 +300,25 @@ struct vy_net {
     off += al(vy_det_scratch_bytes(b, n_items, num_class));
     const size_t pl_off = off;
     size_t fl = 0;
-    for (auto& p : planes) {
+    const std::vector<int> slot = plane_slots(keep_all);
+    std::vector<size_t> slot_off(planes.size(), 0);
+    for (size_t i = 0; i < planes.size(); ++i) {
+      PlaneT& p = planes[i];
       const int ph = cdiv(h, p.div), pw = cdiv(w, p.div);
-      if (commit) {
-        p.H = ph;
-        p.W = pw;
-        p.off = fl;
+      if ((size_t)slot[i] == i) {  // owns its storage (owners come first in definition order: see plane_slots)
+        slot_off[i] = fl;
+        fl += ((size_t)b * (ph + 2) * (pw + 2) * p.C + 63) & ~(size_t)63;
       }
-      fl += ((size_t)b * (ph + 2) * (pw + 2) * p.C + 63) & ~(size_t)63;
+    }
+    for (size_t i = 0; i < planes.size() && commit; ++i) {
+      PlaneT& p = planes[i];
+      p.H = cdiv(h, p.div);
+      p.W = cdiv(w, p.div);
+      p.off = slot_off[slot[i]];
     }
     off += fl * sizeof(float);
     if (commit) {
+      planes_shared = !keep_all;
       fold_desc_off = fold_off;
       det_scratch_off = det_off;
       planes_off = pl_off;
@@ -378,12 +431,10 @@ struct vy_net {
               Hook&& hook) {
     if (int rc = check_ready()) return rc;
     const bool nms_on = nms_thresh > 0.f && nms_thresh < 1.f;  // yolo3.py:1197
-    if (nms_on && nms_topk > VY_MAX_TOPK)
-      return fail(VY_ERR_UNSUPPORTED, "nms_topk must be <= %d, or <= 0 for 'every valid candidate' (got %d)",
-                  VY_MAX_TOPK, nms_topk);
-    if (nms_on && nms_topk <= 0 && (post_nms <= 0 || post_nms > VY_MAX_TOPK))
-      return fail(VY_ERR_UNSUPPORTED, "nms_topk <= 0 needs post_nms in [1, %d] (got %d): the un-sliced output of an "
-                  "unbounded NMS has N*C rows", VY_MAX_TOPK, post_nms);
+    if (nms_on && (nms_topk <= 0 || nms_topk > VY_MAX_TOPK) && (post_nms <= 0 || post_nms > VY_MAX_TOPK))
+      return fail(VY_ERR_UNSUPPORTED, "nms_topk = %d (<= 0: every valid candidate; > %d: consumed in chunks) needs post_nms "
+                  "in [1, %d] (got %d): the kept rows live in one workgroup's LDS, and the un-sliced output of an "
+                  "unbounded NMS has N*C rows", nms_topk, VY_MAX_TOPK, VY_MAX_TOPK, post_nms);
     FoldDesc* fd = reinterpret_cast<FoldDesc*>(dev_ws + fold_desc_off);
     if (!fold_uploaded) {
       HIP_TRY(hipMemcpyAsync(fd, folds.data(), sizeof(FoldDesc) * folds.size(), hipMemcpyHostToDevice, s));

@@ -124,7 +124,7 @@ VyTrain* get_train(vy_net* net) {
 // plan the training regions behind the inference workspace
 size_t train_plan(vy_net* net, int b, int h, int w, bool commit) {
   VyTrain* t = get_train(net);
-  size_t off = al256(net->plan(b, h, w, commit));
+  size_t off = al256(net->plan(b, h, w, commit, /*keep_all=*/true));  // backward reads every activation plane
   // gradient planes mirror the activation planes
   size_t gfl = 0;
   for (auto& p : net->planes) gfl += ((size_t)b * (h / p.div + 2) * (w / p.div + 2) * p.C + 63) & ~(size_t)63;

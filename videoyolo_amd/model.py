@@ -389,6 +389,15 @@ class YOLOV3(object):
         graph.replay()
         return st["ids"].clone(), st["scores"].clone(), st["bboxes"].clone(), st["keep"].clone()
 
+    def keep_activations(self, keep=True):
+        """Parity taps: give every cell its own activation plane so that ``read_activation`` works after an inference
+        forward.  By default inference planes are recycled by liveness (about a third of the workspace at 608x608
+        batch 64), like the intermediates of the reference's hybridized graph; training plans always keep them."""
+        _lib.check(self._lib.vy_net_set_keep_activations(self._h, int(bool(keep))))
+        self._keep_activations = bool(keep)
+        self._plan = None      # the plan changed: size and bind the workspace again at the next call
+        self._graphs = {}
+
     def set_nms(self, nms_thresh=0.45, nms_topk=400, post_nms=100):
         """yolo3.py:1208-1228"""
         self.nms_thresh, self.nms_topk, self.post_nms = nms_thresh, nms_topk, post_nms
@@ -450,6 +459,8 @@ class YOLOV3(object):
         self._grads = self._mom = None
         self._opts_sent = {}
         self._sync_hook, self._sync_bn_checked = None, False  # the new library handle has no callback yet
+        if getattr(self, "_keep_activations", False):
+            _lib.check(self._lib.vy_net_set_keep_activations(self._h, 1))
         for k, v in new_vals.items():
             self._params[k].set_data(v)
         if device is not None:
