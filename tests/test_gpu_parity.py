@@ -494,3 +494,21 @@ def test_recycled_planes_change_nothing_but_the_workspace(voc_classes, synth20, 
     a3 = lean(x, return_index=True)
     assert all(torch.equal(p, q) for p, q in zip(a, a3))
     lean.read_activation("yolo_blocks.1.tip")
+
+
+@pytest.mark.parametrize("tile", ["32x32", "32x64"])
+def test_small_tile_kernel_stays_bit_exact(tile):
+    """conv_small.hip (16x16 wave tiles on v_mfma_f32_16x16x4_f32) is off by default — it measured slower than the
+    32x32 tiles it was built to beat (profiles/r03_negative_results.txt) — but it stays in the library and must stay
+    bit-exact: the head / layer-tap / odd-size tests of this file in a child process that forces every forward conv
+    launch through it (the tile override is read once per process)."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, VY_CONV_FORCE=tile)
+    here = os.path.abspath(__file__)
+    p = subprocess.run([sys.executable, "-m", "pytest", here, "-q", "-x", "-m", "gpu", "-k",
+                        "heads_bit_exact or intermediate_cells or not_multiples_of_32"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900, universal_newlines=True)
+    assert p.returncode == 0, p.stdout[-3000:]
+    assert " passed" in p.stdout

@@ -49,6 +49,9 @@ struct ConvArgs {
 
 // 3x3/1x1 implicit-GEMM convolution on v_mfma_f32_32x32x2_f32.
 hipError_t vy_launch_conv_igemm(const ConvArgs& a, hipStream_t s);
+// the same on 16x16 wave tiles (v_mfma_f32_16x16x4_f32; conv_small.hip): forward launches too small to fill the chip
+// with 32x32 wave tiles.  Block tile bm x bn = 32x32 or 32x64; called by vy_launch_conv_igemm.
+hipError_t vy_launch_conv_s16(const ConvArgs& a, int bm, int bn, hipStream_t s);
 int vy_conv_tiles_m(const ConvArgs& a);
 void vy_conv_cfg(const ConvArgs& a, int* bm, int* bn);  // block tile the launch will use
 

@@ -149,7 +149,7 @@ size_t train_plan(vy_net* net, int b, int h, int w, bool commit) {
       save[i] = sfl;
       sfl += 2 * (size_t)((c.cout + 63) & ~63);
       // partials: forward stats, backward sums
-      const size_t tiles_m = (size_t)((M + 63) / 64);  // per-tile statistics rows: the smallest tile height
+      const size_t tiles_m = (size_t)((M + 31) / 32);  // per-tile statistics rows: the smallest tile height (conv_small.hip)
       size_t pf = 2 * (c.is_stem ? (size_t)vy_stem_blocks(b, h, w) * 64 : tiles_m * 2 * c.cout);  // doubles
       const size_t chunks = (size_t)((M + kBwdChunk - 1) / kBwdChunk);
       if (chunks * 2 * c.cout > pf) pf = chunks * 2 * c.cout;
