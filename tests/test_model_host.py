@@ -290,3 +290,42 @@ def test_record_nested_in_train_mode_is_an_outermost_recording():
                     s.tape.append("inner")
                 assert s.tape == ["inner"]           # a nested record() does not clear
     assert not autograd.is_recording() and not autograd.is_training()
+
+
+def test_pretrained_base_loads_a_darknet53_checkpoint_when_one_is_present(voc_classes, tmp_path):
+    """pretrained_base=True (three_darknet.py:262-264): gluoncv's darknet53-<hash>.params — save_parameters of the
+    ImageNet classifier, names features.<n>... + output.* — found under `root`, read with the mxnet-layout reader,
+    renamed features[:15] / [15:24] / [24:] -> stages.0 / 1 / 2 (wrappers.py:58); the heads are untouched; without a
+    file it only warns (there is no download here)."""
+    from videoyolo_amd import init, mxparams
+    ref = _net(voc_classes[:2])
+    table = [(k, p.shape) for k, p in ref.collect_params().items() if p.backbone]
+    assert len(table) == 52 * 5
+    vals = init.synthetic_params(table, seed=5)
+    ckpt = {}
+    for k, v in vals.items():
+        si, j, rest = k.split(".", 3)[1:]
+        f = int(j) + (0, 15, 24)[int(si)]
+        ckpt["features.%d.%s" % (f, rest)] = v
+    ckpt["output.weight"] = np.zeros((1000, 1024), np.float32)      # the classifier's dense layer: dropped
+    ckpt["output.bias"] = np.zeros((1000,), np.float32)
+    mxparams.save(str(tmp_path / "darknet53-2189ea49.params"), ckpt)
+    net = vy.yolo3_darknet53(voc_classes[:2], pretrained_base=True, root=str(tmp_path))
+    for k, v in vals.items():
+        assert np.array_equal(net.collect_params()[k].data(), v), k
+    with pytest.raises(RuntimeError):
+        net.collect_params()["yolo_blocks.0.body.0.0.weight"].data()   # heads: still to be initialised
+    assert vy.model.darknet53_to_stage_names({"features.14.body.1.0.weight": 1, "features.15.0.weight": 2,
+                                              "features.28.body.0.1.gamma": 3, "output.bias": 4}) == \
+        {"stages.0.14.body.1.0.weight": 1, "stages.1.0.0.weight": 2, "stages.2.4.body.0.1.gamma": 3}
+    with pytest.raises(ValueError):
+        vy.model.darknet53_to_stage_names({"darknetv30_conv0_weight": 1})
+    bad = dict(ckpt)
+    del bad["features.3.0.weight"]
+    mxparams.save(str(tmp_path / "darknet53.params"), bad)
+    os.remove(str(tmp_path / "darknet53-2189ea49.params"))
+    with pytest.raises(AssertionError, match="missing"):
+        vy.yolo3_darknet53(voc_classes[:2], pretrained_base=True, root=str(tmp_path))
+    os.remove(str(tmp_path / "darknet53.params"))
+    with pytest.warns(UserWarning, match="no darknet53"):
+        vy.yolo3_darknet53(voc_classes[:2], pretrained_base=True, root=str(tmp_path))

@@ -202,6 +202,7 @@ struct WgradArgs {
   int a_Hp, a_Wp, a_cs, a_co, stride;
   int k, Cin;             // kernel size, input channels (multiple of 32)
   int splits, k_per_split;  // k_per_split pixels (multiple of 32) per split
+  int xcd_order;          // filled by the launcher: XCD-contiguous (split, tile) order (wgrad.hip)
 };
 hipError_t vy_launch_wgrad(const WgradArgs& a, hipStream_t s);
 // output rows (dz channels) of a weight-gradient block tile: 64 or 128 (the planner's split count depends on it)

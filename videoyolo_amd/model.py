@@ -319,6 +319,25 @@ class YOLOV3(object):
         if ctx is not None:
             self.reset_ctx(ctx)
 
+    def load_darknet53_backbone(self, filename):
+        """``pretrained_base=True`` (three_darknet.py:262-264): load an ImageNet darknet53 checkpoint (gluoncv's
+        ``darknet53-<hash>.params``, mxnet NDArray-dict layout, or an .npz with the same names) into the 52 backbone
+        cells; the heads keep whatever ``initialize()`` gives them (wrappers.py builds them fresh)."""
+        with open(filename, "rb") as f:
+            head = f.read(2)
+        if head == b"PK":
+            with np.load(filename) as z:
+                loaded = {k: z[k] for k in z.files}
+        else:
+            from . import mxparams
+            loaded = mxparams.load(filename)
+        mapped = darknet53_to_stage_names(loaded)
+        want = [k for k, p in self._params.items() if p.backbone]
+        missing = [k for k in want if k not in mapped]
+        if missing:
+            raise AssertionError("Parameter '%s' is missing in %s" % (missing[0], filename))
+        self.set_parameters({k: mapped[k] for k in want}, allow_missing=True)
+
     def set_parameters(self, arrays, allow_missing=False, ignore_extra=False):
         """Load a {structural name: array} dict (reference layouts).  The anchors / offsets Constants of a
         reference checkpoint are checked against the built-in ones (a file made with other anchors cannot be
@@ -822,6 +841,48 @@ class YOLOV3(object):
 YOLOV3T = YOLOV3
 
 
+def _darknet_roots(root=None):
+    """Where ``get_model_file('darknet53', root=...)`` would look: the reference's default root
+    (three_darknet.py:234 ``models/definitions/darknet/weights``), gluoncv's cache, VY_MODEL_ROOT."""
+    roots = [root] if root else []
+    if os.environ.get("VY_MODEL_ROOT"):
+        roots.append(os.environ["VY_MODEL_ROOT"])
+    roots += [os.path.join("models", "definitions", "darknet", "weights"),
+              os.path.join(os.path.expanduser("~"), ".mxnet", "models")]
+    return roots
+
+
+def find_darknet53_file(root=None):
+    """``darknet53-<hash>.params`` (gluoncv's file name) or ``darknet53.params`` in the first root that has one."""
+    import glob
+    for r in _darknet_roots(root):
+        hits = sorted(glob.glob(os.path.join(r, "darknet53-*.params"))) + glob.glob(os.path.join(r, "darknet53.params"))
+        if hits:
+            return hits[0]
+    return None
+
+
+def darknet53_to_stage_names(arrays):
+    """Structural names of a DarknetV3 / Darknet3D checkpoint (``features.<n>...``, ``output.*``: what
+    ``save_parameters`` of the ImageNet classifier writes) -> the detector's names: wrappers.py:58 slices
+    ``features[:15] / [15:24] / [24:]`` into ``stages.0 / 1 / 2``.  The classifier's dense ``output`` layer is dropped
+    (three_darknet.py:263 ``ignore_extra=return_features``).  Older prefix-style names are rejected."""
+    out = {}
+    for k, v in arrays.items():
+        if k.startswith("output."):
+            continue
+        m = re.match(r"^features\.(\d+)\.(.+)$", k)
+        if not m:
+            raise ValueError("'%s' is not a structural DarknetV3 parameter name (features.<n>...): the file was not "
+                             "written by save_parameters of the darknet53 classifier" % k)
+        f = int(m.group(1))
+        if f > 28:
+            raise ValueError("features.%d: darknet53 has 29 feature cells" % f)
+        si, j = (0, f) if f < 15 else ((1, f - 15) if f < 24 else (2, f - 24))
+        out["stages.%d.%d.%s" % (si, j, m.group(2))] = v
+    return out
+
+
 def yolo3_darknet53(classes, pretrained_base=True, norm_layer=BatchNorm, norm_kwargs=None, freeze_base=False,
                     k=None, k_join_type=None, k_join_pos=None, block_conv_type='2', rnn_pos=None,
                     corr_pos=None, corr_d=None, motion_stream=None, add_type=None, agnostic=False,
@@ -846,9 +907,17 @@ def yolo3_darknet53(classes, pretrained_base=True, norm_layer=BatchNorm, norm_kw
         raise NotImplementedError(
             "yolo3_darknet53: option(s) %s select a temporal/two-stream research variant outside the "
             "MI355X hot path" % ", ".join(bad))
-    if pretrained_base:
-        warnings.warn("pretrained_base=True: no model-zoo access offline; backbone left uninitialised")
+    root = kwargs.pop("root", None)
     net = YOLOV3(classes, norm_layer=norm_layer, norm_kwargs=norm_kwargs, **kwargs)
+    if pretrained_base:
+        # three_darknet.py:262-264: net.load_parameters(get_model_file('darknet53', tag=pretrained, root=root)).  There is
+        # no model-zoo download here: the file must already be where gluoncv would have cached it.
+        path = find_darknet53_file(root)
+        if path is None:
+            warnings.warn("pretrained_base=True: no darknet53-*.params under %s (gluoncv would download it; there is no "
+                          "network access here) — backbone left to initialize() / load_parameters()" % (_darknet_roots(root),))
+        else:
+            net.load_darknet53_backbone(path)
     if freeze_base:  # wrappers.py:55-57
         for p in net.collect_params().values():
             if p.backbone:
