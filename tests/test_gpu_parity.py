@@ -483,7 +483,8 @@ def test_recycled_planes_change_nothing_but_the_workspace(voc_classes, synth20, 
     b = keep(x, return_index=True)
     hb = [keep.read_head(i) for i in range(3)]
     assert all(torch.equal(p, q) for p, q in zip(a, b)) and all(torch.equal(p, q) for p, q in zip(ha, hb))
-    assert lean._ws.numel() < 0.6 * keep._ws.numel(), (lean._ws.numel(), keep._ws.numel())
+    fixed = (32 << 20) + 8192          # the stream-K scratch both plans carry (kernels.h VY_SK_PARTIAL_BYTES + flags)
+    assert lean._ws.numel() - fixed < 0.6 * (keep._ws.numel() - fixed), (lean._ws.numel(), keep._ws.numel())
     with pytest.raises(_lib.VyError, match="recycled"):
         lean.read_activation("stages.0.2.body.1")
     keep.read_activation("stages.0.2.body.1")
@@ -510,5 +511,24 @@ def test_small_tile_kernel_stays_bit_exact(tile):
     p = subprocess.run([sys.executable, "-m", "pytest", here, "-q", "-x", "-m", "gpu", "-k",
                         "heads_bit_exact or intermediate_cells or not_multiples_of_32"],
                        env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900, universal_newlines=True)
+    assert p.returncode == 0, p.stdout[-3000:]
+    assert " passed" in p.stdout
+
+
+def test_stream_k_hand_off_stays_bit_exact():
+    """The chain-preserving stream-K instances of conv_igemm.hip (a tile started by one block, its accumulators handed
+    over through a slab + flag, finished by the next block with the SAME fma chain) are off by default — measured
+    neutral-to-slower (profiles/r03_negative_results.txt) — but stay in the library: with VY_CONV_SK=1 and
+    VY_CONV_SK_SLOTS=5 every conv launch of more than 5 tiles runs on 5 blocks, so even the small shapes of this file
+    go through head / whole / tail items and the hand-off.  Heads, layer taps, odd sizes, one training step."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, VY_CONV_SK="1", VY_CONV_SK_SLOTS="5")
+    here = os.path.dirname(os.path.abspath(__file__))
+    p = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_parity.py"),
+                        os.path.join(here, "test_gpu_train_parity.py"), "-q", "-x", "-m", "gpu", "-k",
+                        "heads_bit_exact or intermediate_cells or not_multiples_of_32 or train_step_matches_oracle"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=1200, universal_newlines=True)
     assert p.returncode == 0, p.stdout[-3000:]
     assert " passed" in p.stdout

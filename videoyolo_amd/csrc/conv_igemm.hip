@@ -40,15 +40,22 @@
 
 #include "conv_device.h"
 
-template <int BM, int BN, int WM, int WN, bool DGRAD, int NS = 2>
-// NS = LDS stages.  2: the throughput configuration (2-4 resident blocks per CU hide each other's DMA latency).
-// 4: for launches of so few blocks that a CU holds one (batch 1, the 13x13 maps at batch 16): the k-step of a lone
-// 64x64 block is 0.43 us of matrix work but a DMA takes ~0.8 us to land, so three k-steps are kept in flight.
-// 2nd launch-bounds argument = waves per SIMD the register allocation must allow: two (2 blocks/CU of 4
-// waves, or one 8-wave block).  Without it hipcc let the register count drift past 256 and silently
-// halved the occupancy of some variants.
-__global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_kernel(const ConvArgs a, const int tiles_n) {
-#if defined(__HIP_DEVICE_COMPILE__)  // the host pass only needs the launch stub (amdgcn builtins below)
+// Stream-K hand-off between the block that starts a tile and the block that finishes it (SK instances only).
+// `per` k-steps per block, `T` k-steps per tile, `tiles` tiles; partials: [grid][BM * BN] floats; flags: [grid] words,
+// zero between launches (the consumer clears the flag it waited for).
+struct SkArgs {
+  float* partials;
+  unsigned* flags;
+  int per, tiles;
+};
+
+// One tile of the implicit GEMM, k-steps [kb, ke): from zero or (SK) from the previous block's partial sums, to the
+// epilogue or (SK) to this block's partial slab.  `Args` is ConvArgs in the address space the caller reads it from.
+template <int BM, int BN, int WM, int WN, bool DGRAD, int NS, bool SK, typename Args>
+__device__ __forceinline__ void conv_tile(Args& a, const int tiles_n, const SkArgs& sk, unsigned char* smem,
+                                          const int vblk, const int v, const int kb, const int ke,
+                                          const bool load_partial, const bool store_partial) {
+#if defined(__HIP_DEVICE_COMPILE__)
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
   constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
   constexpr int NW = WM * WN, NT = NW * 64;               // waves / threads per block
@@ -56,8 +63,6 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_kernel(const ConvA
   static_assert(NW == 4 || NW == 8, "4 or 8 waves");
   static_assert(A_INSTR >= 1 && B_INSTR >= 1, "tile too small for the wave count");
   static_assert(TM >= 1 && TN >= 1, "tile");
-  // one LDS object: [stage0 A|W][stage1 A|W]...[row tables]
-  __shared__ __attribute__((aligned(16))) unsigned char smem[NS * STAGE + 2 * BM * 8];
   long long* in_off = reinterpret_cast<long long*>(smem + NS * STAGE);
   // epilogue row tables: byte offset of the row's output pixel (and of its addend pixel) relative to the
   // tile's first pixel; kInvalidRow for rows past M.  The epilogue addresses memory through buffer
@@ -68,7 +73,12 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_kernel(const ConvA
   unsigned* r_off = o_off + BM;
   constexpr unsigned kInvalidRow = 0x80000000u;
 
-  const int tid = threadIdx.x;
+  int tid_ = threadIdx.x;
+  // SK: the tile body runs in a loop over work items.  Everything derived from the thread index is loop-invariant, and
+  // hipcc hoists it all out of the loop and keeps it live (fragment addresses, swizzles, epilogue columns: 78 -> 140
+  // VGPRs for the 64x64 tile, spills for 128x128, an occupancy step lost).  Opaque per item, it is recomputed instead.
+  if (SK) asm volatile("" : "+v"(tid_));
+  const int tid = tid_;
 #ifdef VY_CONV_TRACE  // tools/probe/conv_tile_trace.hip: thread 0 stamps the tile's phases (never compiled into the library)
 #define VY_TRACE(slot) \
   if (a.trace && tid == 0) a.trace[(long long)blockIdx.x * 8 + (slot)] = __builtin_amdgcn_s_memrealtime();
@@ -80,15 +90,9 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_kernel(const ConvA
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
   const int h = lane >> 5;
+  const int cchunks = a.Kc >> 5;
 
-  // XCD-aware tile order: blocks L, L+8, ... share an XCD (L2); give each XCD a contiguous run
-  // of tiles with n fastest so neighbours in time re-use the same A rows and the whole W panel.
-  int v;
-  {
-    const int nblk = gridDim.x, L = blockIdx.x;
-    const int q = nblk >> 3, r = nblk & 7, xcd = L & 7, idx = L >> 3;
-    v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  }
+  if (SK) __syncthreads();  // the previous item's epilogue is done with the row tables
   const int tile_m = v / tiles_n, tile_n = v - tile_m * tiles_n;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
@@ -164,24 +168,46 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_kernel(const ConvA
   }
 
   f32x16 acc[TM][TN];
+  if constexpr (SK) {
+    // The head of a continued tile was computed by block vblk - 1 as its FIRST work item.  One lane polls its flag, then
+    // an agent-scope acquire, then the loads.  The loads are issued for EVERY item, through a buffer descriptor whose
+    // range is 0 unless this item continues a tile: out-of-range loads return 0.0f without touching memory — the
+    // accumulators have ONE definition (a branch here made hipcc keep two copies of them: 2x the registers).
+    if (load_partial && tid == 0) {
+      while (__hip_atomic_load(sk.flags + (vblk - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u)
+        __builtin_amdgcn_s_sleep(8);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    if (load_partial) __syncthreads();
+    const __amdgpu_buffer_rsrc_t slab = __builtin_amdgcn_make_buffer_rsrc(
+        sk.partials + (size_t)(vblk > 0 ? vblk - 1 : 0) * (BM * BN), 0, load_partial ? BM * BN * 4 : 0, 0x00020000);
 #pragma unroll
-  for (int i = 0; i < TM; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < TN; ++j)
+      for (int j = 0; j < TN; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = buf_load_f32(slab, (unsigned)((((i * TN + j) * 16 + r) * NT + tid) * 4));
+    // (the flag is cleared for the next launch once every thread has its values: after the k-loop, see below)
+  } else {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+  }
 
   // LDS byte address of smem (a 32-bit LDS pointer), wave-uniform
   const unsigned lds0 = (unsigned)(unsigned long long)LDS_PTR(smem);
-  const int cchunks = a.Kc >> 5;
-  const int T = a.ntaps * cchunks;
+  const int T = ke - kb;
 
   const int lrow = lane & 31;
   // ---- k-loop.  Wave-uniform tile state (tap, channel chunk -> A / W offsets) is advanced once per tile
   // with scalar arithmetic; the last tile is peeled (no prefetch); fragments are double-buffered in
   // registers; sched_barriers pin the order  [MFMA steps 0,1] [a third of the next tile's DMA] [step 2]
   // [next group's ds_reads] [step 3]  per 8-channel group.
-  int n_tap = 0, n_cc = 0;
+  int n_tap = SK ? kb / cchunks : 0, n_cc = SK ? kb - (kb / cchunks) * cchunks : 0;
   int a_koff = 0;          // floats; |(dy * Wp + dx) * cs| < 2^23: 32-bit scalar arithmetic
   long long b_koff = 0;
   bool n_lastcc = false;
@@ -352,6 +378,27 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_kernel(const ConvA
   }
 
   VY_TRACE(2)
+  if (SK && load_partial && tid == 0)  // every thread passed a k-loop barrier after loading its partial sums
+    __hip_atomic_store(sk.flags + (vblk - 1), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (SK && store_partial) {
+    // head piece: the accumulators go to this block's slab; plain stores, every wave drains them, one lane publishes
+    // (agent-scope release, drained, then the flag) — MI355X_MICROARCH.md, inter-workgroup visibility
+    float* slab = sk.partials + (size_t)vblk * (BM * BN);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) slab[((i * TN + j) * 16 + r) * NT + tid] = acc[i][j][r];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __hip_atomic_store(sk.flags + vblk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return;
+  }
   // epilogue: affine (folded BN or bias) -> leaky -> + addend -> store (x1 or x2-replicated), through
   // buffer descriptors based at the tile's first pixel and column (see the row tables above)
   constexpr int kRsrcFlags = 0x00020000;  // raw dword buffer, gfx9 data format 32
@@ -488,15 +535,141 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_kernel(const ConvA
 #endif  // __HIP_DEVICE_COMPILE__
 }
 
+template <int BM, int BN, int WM, int WN, bool DGRAD, int NS = 2, bool SK = false>
+// SK = chain-preserving stream-K.  A plain launch hands whole tiles to the CUs, so a launch of 2.66 x 256 tiles costs three
+// rounds.  The SK instance is launched with exactly as many blocks as the chip holds; the sequence of all k-steps (tile
+// 0's, tile 1's, ...) is cut into equal contiguous shares, one per block, so a block owns [the tail of a tile][whole
+// tiles][the head of a tile].  It runs them in the order HEAD, whole tiles, TAIL: the head piece (k-steps 0 .. k1 of its
+// last tile) first — its 16 accumulator registers per MFMA tile go to a scratch slab and a flag is raised; the tail piece
+// (k-steps k0 .. T of its first tile) last — it waits for the previous block's flag (raised long ago: that block did the
+// head first), loads the accumulators as the MFMA C operand and continues the SAME fma chain, then runs the normal
+// epilogue.  Every output element is still one fma chain in the pinned order: results are bit-identical to the plain launch.
+// NS = LDS stages.  2: the throughput configuration (2-4 resident blocks per CU hide each other's DMA latency).
+// 4: for launches of so few blocks that a CU holds one (batch 1, the 13x13 maps at batch 16): the k-step of a lone
+// 64x64 block is 0.43 us of matrix work but a DMA takes ~0.8 us to land, so three k-steps are kept in flight.
+// 2nd launch-bounds argument = waves per SIMD the register allocation must allow: two (2 blocks/CU of 4
+// waves, or one 8-wave block).  Without it hipcc let the register count drift past 256 and silently
+// halved the occupancy of some variants.
+__global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_kernel(const ConvArgs a, const int tiles_n, const SkArgs sk) {
+#if defined(__HIP_DEVICE_COMPILE__)  // the host pass only needs the launch stub (amdgcn builtins below)
+  constexpr int STAGE = (BM + BN) * 128;
+  // one LDS object: [stage0 A|W][stage1 A|W]...[row tables]
+  __shared__ __attribute__((aligned(16))) unsigned char smem[NS * STAGE + 2 * BM * 8];
+  // XCD-aware order: blocks L, L+8, ... share an XCD (L2); give each XCD a contiguous run of tiles (SK: of the
+  // k-step sequence) with n fastest so neighbours in time re-use the same A rows and the whole W panel.
+  int vblk;
+  {
+    const int nblk = gridDim.x, L = blockIdx.x;
+    const int q = nblk >> 3, r = nblk & 7, xcd = L & 7, idx = L >> 3;
+    vblk = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int T_all = a.ntaps * (a.Kc >> 5);  // k-steps of a whole tile
+
+
+  if constexpr (!SK) {
+    conv_tile<BM, BN, WM, WN, DGRAD, NS, SK, const ConvArgs>(a, tiles_n, sk, smem, vblk, vblk, 0, T_all, false, false);
+  } else {
+    // this block's share of the k-step sequence: [it0, it1), at least one whole tile long (per >= T_all)
+    const long long total = (long long)sk.tiles * T_all;
+    const long long it0 = (long long)vblk * sk.per;
+    if (it0 >= total) return;
+    const long long it1 = it0 + sk.per < total ? it0 + sk.per : total;
+    const int first = (int)(it0 / T_all), k0 = (int)(it0 - (long long)first * T_all);
+    const int last = (int)((it1 - 1) / T_all), k1 = (int)(it1 - (long long)last * T_all);  // k1 in (0, T_all]
+    // work items in running order: [HEAD of the last tile] [whole tiles] [TAIL of the first tile]; a share inside one
+    // tile (only the final remainder with per >= T_all) is that tile's tail
+    int hb, w0, nw, tail, tk1;
+    if (first == last) {
+      hb = 0, w0 = 0, nw = 0, tail = 1, tk1 = k1;
+    } else {
+      hb = k1 < T_all ? 1 : 0;
+      w0 = k0 == 0 ? first : first + 1;
+      nw = (k1 == T_all ? last : last - 1) - w0 + 1;
+      tail = k0 > 0 ? 1 : 0;
+      tk1 = T_all;
+    }
+    const int n_items = hb + nw + tail;
+    for (int it = 0; it < n_items; ++it) {  // ONE call site: the tile body is instantiated once
+      int tile, kb, ke;
+      bool ld, st;
+      if (it < hb) {
+        tile = last, kb = 0, ke = k1, ld = false, st = true;
+      } else if (it < hb + nw) {
+        tile = w0 + (it - hb), kb = 0, ke = T_all, ld = false, st = false;
+      } else {
+        tile = first, kb = k0, ke = tk1, ld = k0 > 0, st = tk1 < T_all;
+      }
+      // The arguments are read through the kernarg pointer, made opaque once per item: with `a` itself every field
+      // (and everything derived from it) stayed live across the whole loop, the SGPRs ran out and spilled into
+      // vector registers (78 -> 151 VGPRs for the 64x64 tile, scratch for 128x128, an occupancy step lost)
+      typedef const __attribute__((address_space(4))) ConvArgs KArgs;
+      KArgs* ap = (KArgs*)__builtin_amdgcn_kernarg_segment_ptr();  // ConvArgs is the first argument
+      asm volatile("" : "+s"(ap));
+      conv_tile<BM, BN, WM, WN, DGRAD, NS, SK, KArgs>(*ap, tiles_n, sk, smem, vblk, tile, kb, ke, ld, st);
+    }
+  }
+#endif  // __HIP_DEVICE_COMPILE__
+}
+
+// blocks of an instance one CU holds, and the CU count (queried once)
+template <typename K>
+static int resident_blocks(K kernel, int threads) {
+  int n = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, threads, 0) != hipSuccess || n < 1) n = 1;
+  return n;
+}
+static int cu_count() {
+  static int n = [] {
+    int dev = 0, c = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || c < 1)
+      c = 256;
+    return c;
+  }();
+  return n;
+}
+
 template <int BM, int BN, int WM, int WN, int NS = 2>
 static hipError_t launch_cfg(const ConvArgs& a, hipStream_t s) {
   const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + BN - 1) / BN;
+  const long long tiles = (long long)tiles_m * tiles_n;
+  SkArgs sk = {nullptr, nullptr, 0, 0};
+  // Stream-K when the launch has more tiles than the chip holds blocks and its last round of the CUs is poorly filled:
+  // a CU works through tiles / CUs tiles, rounded UP in a plain launch (the cost model of select_cfg)
+  // OFF by default: measured on one box (profiles/r03_negative_results.txt) +0.4 % at 608x608 batch 64 (the 19x19 layers:
+  // 5.66 -> 6 rounds), -3 % at 416x416 batch 64 and -2 % in the training step — a static share per block gives up the
+  // hardware's dynamic tile scheduling, and a block with 2.7 tiles of work pays three prologues and a hand-off for them.
+  static const int sk_on = getenv("VY_CONV_SK") ? atoi(getenv("VY_CONV_SK")) : 0;
+  static const double sk_min_gain = getenv("VY_CONV_SK_GAIN") ? atof(getenv("VY_CONV_SK_GAIN")) : 0.03;
+  if (sk_on && a.sk_partials && a.sk_flags && NS == 2) {
+    static const int res_f = resident_blocks(conv_igemm_kernel<BM, BN, WM, WN, false, NS, true>, WM * WN * 64);
+    static const int res_d = resident_blocks(conv_igemm_kernel<BM, BN, WM, WN, true, NS, true>, WM * WN * 64);
+    // test switch: VY_CONV_SK_SLOTS=n runs every launch of more than n tiles on n blocks (small shapes through the hand-off)
+    static const int sk_slots = getenv("VY_CONV_SK_SLOTS") ? atoi(getenv("VY_CONV_SK_SLOTS")) : 0;
+    const int cus = cu_count();
+    const long long G = sk_slots > 0 ? sk_slots : (long long)cus * (a.dgrad ? res_d : res_f);
+    const double rounds = (double)tiles / cus, plain = (double)((tiles + cus - 1) / cus);
+    const int T = a.ntaps * (a.Kc >> 5);
+    if (tiles > G && (sk_slots > 0 || (plain - rounds) / plain >= sk_min_gain) && G * BM * BN * 4ll <= (long long)a.sk_bytes &&
+        G <= a.sk_nflags) {
+      sk.partials = a.sk_partials;
+      sk.flags = a.sk_flags;
+      sk.tiles = (int)tiles;
+      sk.per = (int)((tiles * T + G - 1) / G);  // >= T because tiles > G
+      if (a.dgrad)
+        hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, true, NS, true>), dim3((unsigned)G), dim3(WM * WN * 64), 0, s,
+                           a, tiles_n, sk);
+      else
+        hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, false, NS, true>), dim3((unsigned)G), dim3(WM * WN * 64), 0, s,
+                           a, tiles_n, sk);
+      return hipGetLastError();
+    }
+  }
   if (a.dgrad)
     hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, true, NS>), dim3(tiles_m * tiles_n), dim3(WM * WN * 64), 0, s,
-                       a, tiles_n);
+                       a, tiles_n, sk);
   else
     hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, false, NS>), dim3(tiles_m * tiles_n), dim3(WM * WN * 64), 0, s,
-                       a, tiles_n);
+                       a, tiles_n, sk);
   return hipGetLastError();
 }
 

@@ -45,7 +45,14 @@ struct ConvArgs {
   unsigned long long* trace;    // tools/probe/conv_tile_trace.hip only: [block][8] phase timestamps (100 MHz) + CU id
 #endif
   unsigned long long pk_w;      // 4 bits / tap
+  // stream-K scratch of the net's workspace (nullable: plain launches only): partial accumulator slabs + hand-off flags
+  float* sk_partials;
+  unsigned* sk_flags;
+  unsigned long long sk_bytes;  // bytes of sk_partials
+  int sk_nflags;
 };
+#define VY_SK_PARTIAL_BYTES (32u << 20)  // 512 blocks x 128x128 fp32 (the largest instance: 2 blocks per CU x 256 CUs)
+#define VY_SK_FLAGS 2048
 
 // 3x3/1x1 implicit-GEMM convolution on v_mfma_f32_32x32x2_f32.
 hipError_t vy_launch_conv_igemm(const ConvArgs& a, hipStream_t s);

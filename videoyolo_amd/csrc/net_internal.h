@@ -70,7 +70,7 @@ struct vy_net {
   unsigned char* dev_ws = nullptr;
   size_t ws_bytes = 0;
   int B = 0, H = 0, W = 0;
-  size_t fold_desc_off = 0, det_scratch_off = 0, planes_off = 0;  // byte offsets in workspace
+  size_t fold_desc_off = 0, det_scratch_off = 0, planes_off = 0, sk_off = 0;  // byte offsets in workspace
   bool fold_uploaded = false;
   bool keep_activations = false;  // vy_net_set_keep_activations: inference planes are not recycled (parity taps)
   bool planes_shared = false;     // the committed plan recycles planes (read_activation is then meaningless)
@@ -298,6 +298,8 @@ struct vy_net {
     auto cdiv = [](int a, int d) { return (a + d - 1) / d; };
     for (int i = 0; i < 3; ++i) n_items += 3 * cdiv(h, planes[head_plane[i]].div) * cdiv(w, planes[head_plane[i]].div);
     off += al(vy_det_scratch_bytes(b, n_items, num_class));
+    const size_t sk_o = off;  // stream-K scratch of the conv launches (conv_igemm.hip): flags first, then the slabs
+    off += al((size_t)VY_SK_FLAGS * sizeof(unsigned)) + al(VY_SK_PARTIAL_BYTES);
     const size_t pl_off = off;
     size_t fl = 0;
     const std::vector<int> slot = plane_slots(keep_all);
@@ -321,6 +323,7 @@ struct vy_net {
       planes_shared = !keep_all;
       fold_desc_off = fold_off;
       det_scratch_off = det_off;
+      sk_off = sk_o;
       planes_off = pl_off;
       B = b;
       H = h;
@@ -391,7 +394,16 @@ struct vy_net {
     }
     a.leaky = c.leaky;
     a.dgrad = 0;
+    set_sk(a);
     return a;
+  }
+
+  // the stream-K scratch of this net's workspace (zeroed with the workspace at bind time: all flags down)
+  void set_sk(ConvArgs& a) const {
+    a.sk_flags = reinterpret_cast<unsigned*>(dev_ws + sk_off);
+    a.sk_partials = reinterpret_cast<float*>(dev_ws + sk_off + al((size_t)VY_SK_FLAGS * sizeof(unsigned)));
+    a.sk_bytes = VY_SK_PARTIAL_BYTES;
+    a.sk_nflags = VY_SK_FLAGS;
   }
 
   DetArgs det_args() const {

@@ -456,6 +456,7 @@ BwdDgrad make_dgrad(const TrainCtx& c, const ConvT& cv, const float* dzp, int dz
   a.o_co = cv.in_co;
   a.ups = 1;
   a.dgrad = 1;
+  net->set_sk(a);
   if (cv.stride == 1) {
     a.LH = ip.H;
     a.LW = ip.W;

@@ -98,7 +98,13 @@ def make_host_group():
     if dist.get_backend() == "gloo":
         _host_group = dist.group.WORLD
     else:
-        _host_group = dist.new_group(backend="gloo")
+        try:
+            _host_group = dist.new_group(backend="gloo")
+        except Exception as e:  # no usable host interface for gloo: every rank of the node fails alike
+            import warnings
+            warnings.warn("no gloo side group (%s): control-plane agreement falls back to one-element RCCL all-reduces "
+                          "with a host read-back per recorded forward" % e)
+            _host_group = False
     return _host_group
 
 
@@ -110,7 +116,7 @@ def any_rank(flag, device=None):
         return bool(flag)
     import torch
     dist = _dist()
-    if _host_group is not None:
+    if _host_group:
         t = torch.tensor([1 if flag else 0], dtype=torch.int32)
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=_host_group)
         return bool(t.item())
