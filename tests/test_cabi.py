@@ -68,12 +68,19 @@ def test_planning_and_argument_errors():
     lib = _lib.load()
     h = ctypes.c_void_p()
     _lib.check(lib.vy_net_create(20, ctypes.byref(h)))
+    fixed = (32 << 20) + 8192      # stream-K scratch (kernels.h VY_SK_PARTIAL_BYTES + flags): in every plan
+    # one plane per cell (parity taps / training): the conv-output activations, 38.6 M floats / frame at 416
+    #  + borders + scratch
+    _lib.check(lib.vy_net_set_keep_activations(h, 1))
+    k1 = lib.vy_net_workspace_bytes(h, 1, 416, 416) - fixed
+    assert 38.6e6 * 4 < k1 < 1.25 * 38.6e6 * 4 + 4e6
+    # the default inference plan recycles planes by liveness: little more than half of that
+    _lib.check(lib.vy_net_set_keep_activations(h, 0))
     b1 = lib.vy_net_workspace_bytes(h, 1, 416, 416)
     b2 = lib.vy_net_workspace_bytes(h, 2, 416, 416)
     b608 = lib.vy_net_workspace_bytes(h, 1, 608, 608)
-    # conv-output activations: 38.6 M floats / frame at 416 + borders + scratch
-    assert 38.6e6 * 4 < b1 < 1.25 * 38.6e6 * 4 + 4e6
-    assert b1 < b2 < 2 * b1 + 1e6 and b608 > 2 * b1
+    assert 0.45 * k1 < b1 - fixed < 0.6 * k1
+    assert b1 < b2 < 2 * b1 + 1e6 and b608 - fixed > 2 * (b1 - fixed)
     # inference plans any size in [32, 4096] (ceil-sized feature maps, cropped upsample); training multiples of 32
     b400 = lib.vy_net_workspace_bytes(h, 1, 400, 416)
     assert lib.vy_net_workspace_bytes(h, 1, 384, 416) < b400 < b1
