@@ -776,6 +776,12 @@ hipError_t vy_launch_conv_igemm(const ConvArgs& a_in, hipStream_t s) {
   int bm, bn;
   select_cfg(a, &bm, &bn);
   if (bm == 32) return vy_launch_conv_s16(a, bm, bn, s);
+  // experiment switch: VY_CONV_S16=1 sends a forced tile (VY_CONV_FORCE) through the 16x16x4 kernel where it has the instance
+  static const int s16_forced = getenv("VY_CONV_S16") ? atoi(getenv("VY_CONV_S16")) : 0;
+  if (s16_forced && !a.dgrad && (bm % 32 == 0) && (bn == 64 || bn == 96)) {
+    const hipError_t e = vy_launch_conv_s16(a, bm, bn, s);
+    if (e != hipErrorInvalidValue) return e;
+  }
   if (bn == 32) return launch_cfg<128, 32, 4, 1>(a, s);
   if (bm == 128 && bn == 64) return launch_cfg<128, 64, 2, 2>(a, s);
   if (bm == 64) {
