@@ -13,6 +13,7 @@
 // half-wave (conflict-free, no swizzle).  Block tile 128(o) x 128(n) x 32(p), 4 waves 2x2,
 // 64 accumulator VGPRs per lane, 64 KiB LDS double buffer -> 2 blocks / CU.
 #include <cstdlib>
+#include <type_traits>
 
 #include "kernels.h"
 
@@ -161,43 +162,70 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a, const 
     for (int j = 0; j < NJ; ++j) stage(0, j);
     if (T > 1) load_offsets(1);
   }
-  for (int t = 0; t < T; ++t) {
+  // One k-step on the tile in buffer PAR (a compile-time constant: the loop below is unrolled by two, so the buffer
+  // offset folds into the ds_read immediates — round 2's loop added it to every fragment address, 38 vector adds per
+  // 32 MFMAs in the 64-row instance).  The fragments of group g + 1 are read while the MFMAs of group g run (two
+  // register sets): before, every group read its fragments and waited for them, four exposed LDS latencies per
+  // k-step (SQ counters of round 3: 55 % MFMA-busy for the 64-row instance, 76 % for the 128-row one).
+  struct Frag {
+    f32x2 av[4];
+    float bv[4][TJ];
+  };
+  auto kstep = [&](auto par_, const int t) {
+    constexpr int PAR = decltype(par_)::value;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of tile t has landed
     __syncthreads();
     const bool more = t + 1 < T;
-    const float* tA = reinterpret_cast<const float*>(smem + (t & 1) * STAGE);
+    const float* tA = reinterpret_cast<const float*>(smem + PAR * STAGE);
     const float* tB = tA + KP * BM;
-#pragma unroll
-    for (int g = 0; g < NJ; ++g) {
-      // one ds_read_b64 per operand and pixel pair: lane lrow gets rows / columns 2*lrow and 2*lrow+1 of the
-      // wave's 64, so MFMA tile m of an operand covers the interleaved set {2*l + m} (undone in the epilogue);
-      // BM = 64: the wave's 32 n columns are read one float per lane
-      f32x2 av[4];
-      float bv[4][TJ];
+    // one ds_read_b64 per operand and pixel pair: lane lrow gets rows / columns 2*lrow and 2*lrow+1 of the
+    // wave's 64, so MFMA tile m of an operand covers the interleaved set {2*l + m} (undone in the epilogue);
+    // BM = 64: the wave's 32 n columns are read one float per lane
+    auto load_group = [&](Frag& f, const int g) {
 #pragma unroll
       for (int s4 = 0; s4 < 4; ++s4) {
         const int kpix = 2 * (g * 4 + s4) + h;
-        av[s4] = *reinterpret_cast<const f32x2*>(tA + kpix * BM + wm * 64 + 2 * lrow);
+        f.av[s4] = *reinterpret_cast<const f32x2*>(tA + kpix * BM + wm * 64 + 2 * lrow);
         if (BM == 128) {
           const f32x2 b2 = *reinterpret_cast<const f32x2*>(tB + kpix * 128 + wn * 64 + 2 * lrow);
-          bv[s4][0] = b2[0];
-          bv[s4][TJ - 1] = b2[1];
+          f.bv[s4][0] = b2[0];
+          f.bv[s4][TJ - 1] = b2[1];
         } else {
-          bv[s4][0] = tB[kpix * 128 + wn * 32 + lrow];
+          f.bv[s4][0] = tB[kpix * 128 + wn * 32 + lrow];
         }
       }
+    };
+    Frag f0, f1;
+    load_group(f0, 0);
+#pragma unroll
+    for (int g = 0; g < NJ; ++g) {
+      Frag& cur = (g & 1) ? f1 : f0;
+      Frag& nxt = (g & 1) ? f0 : f1;
+      __builtin_amdgcn_sched_barrier(0);
+      if (g + 1 < NJ) load_group(nxt, g + 1);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int s4 = 0; s4 < 4; ++s4) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
           for (int j = 0; j < TJ; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s4][i], bv[s4][j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.av[s4][i], cur.bv[s4][j], acc[i][j], 0, 0, 0);
         // a quarter of the next tile's DMA, issued while this group's MFMAs occupy the matrix pipe
-        if (s4 == 0 && more) stage((t + 1) & 1, g);
+        if (s4 == 0 && more) stage(PAR ^ 1, g);
       }
     }
-    if (t + 2 < T) load_offsets(t + 2);  // consumed by the stage() calls of the next iteration, after its vmcnt(0)
+    if (t + 2 < T) load_offsets(t + 2);  // consumed by the stage() calls of the next k-step, after its vmcnt(0)
+  };
+  {
+    using P0 = std::integral_constant<int, 0>;
+    using P1 = std::integral_constant<int, 1>;
+    int t = 0;
+    for (; t + 1 < T; t += 2) {
+      kstep(P0{}, t);
+      kstep(P1{}, t + 1);
+    }
+    if (t < T) kstep(P0{}, t);
   }
 
   float* slab = a.slabs + (long long)split * a.Cout * Ntot;
