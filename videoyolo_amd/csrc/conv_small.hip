@@ -208,14 +208,15 @@ __global__ __launch_bounds__(256, 2) void conv_s16_kernel(const ConvArgs a, cons
       }
     }
   };
-  // the per-quarter select: ONE v_cndmask_b32 on a wave-uniform lane mask.  Written as `hi ? v[1] : v[0]`, hipcc
-  // canonicalises it to a variable-index element extract and emits three compares + three selects per value
-  // (9.4 M vector instructions per launch against 1.8 M MFMAs on the 19x19 layer: the kernel was VALU-bound)
-  const unsigned long long hi_mask = __builtin_amdgcn_ballot_w64(hi);
+  // the per-quarter select: ONE v_cndmask_b32.  Written plainly as `hi ? v[1] : v[0]`, hipcc canonicalises it to a
+  // variable-index element extract and emits three compares + three selects per value (9.4 M vector instructions per
+  // launch against 1.8 M MFMAs on the 19x19 layer: the kernel was VALU-bound).  The empty asm makes the two elements
+  // opaque scalars, so the select stays a select — and stays a compiler-generated VALU instruction: an inline-asm
+  // v_cndmask is invisible to the hazard recognizer, which then leaves out the wait states between a VALU write and
+  // the MFMA that reads it (measured: NaNs).
   auto pick = [&](float lo_half, float hi_half) -> float {
-    float r;
-    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(lo_half), "v"(hi_half), "s"(hi_mask));
-    return r;
+    asm("" : "+v"(lo_half), "+v"(hi_half));
+    return hi ? hi_half : lo_half;
   };
   // 4 groups of MFMAs on the fragments of sub-step t.  Behind group 0: the barrier of sub-step t + 1 and the reads of its
   // fragments (`after_group0`); behind groups 1 .. 3 a share each of the LDS-DMA of sub-step t + NS, into the buffer
