@@ -532,3 +532,25 @@ def test_stream_k_hand_off_stays_bit_exact():
                        env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=1200, universal_newlines=True)
     assert p.returncode == 0, p.stdout[-3000:]
     assert " passed" in p.stdout
+
+
+@pytest.mark.parametrize("topk,post", [(400, 100), (-1, 100), (3000, 50)])
+def test_no_valid_candidate_at_all(voc_classes, topk, post):
+    """Objectness biases of -30: every score is far below valid_thresh = 0.01, so box_nms has nothing to sort — all
+    three NMS paths (radix-select + bitonic, the unbounded chunked kernel, the capped chunked kernel) must return rows
+    of -1 only, like the oracle, and must not touch stale state of a previous call with thousands of candidates."""
+    from videoyolo_amd import init
+    from oracle import yolo3_oracle as O
+    table = O.param_shapes(20)
+    x = frames(2, 96, seed=3)
+    busy = _net(voc_classes, init.synthetic_params(table, seed=233))
+    busy.set_nms(0.45, topk, post)
+    first = busy(x, return_index=True)
+    assert int((first[3] >= 0).sum()) > 0
+    params = init.synthetic_params(table, seed=233, obj_bias=-30.0)
+    busy.set_parameters(params)                                  # same net object, same workspace: now silent
+    ids, scores, bboxes, keep = [t.cpu().numpy() for t in busy(x, return_index=True)]
+    r = _oracle(params, nms_topk=topk, post_nms=post)(x)
+    assert (r[3] < 0).all(), "the constructed case must have no valid candidate"
+    assert (keep == -1).all() and (ids == -1).all() and (scores == -1).all() and (bboxes == -1).all()
+    assert ids.shape == (2, post, 1) and bboxes.shape == (2, post, 4)

@@ -333,3 +333,36 @@ def test_reset_class_on_device():
     ids, scores, bboxes = net(x)
     assert ids.shape == (B, 100, 1)
     assert float(ids.max()) <= 1.0
+
+
+def test_image_without_ground_truth_boxes():
+    """A batch in which one image has NO object (every gt row is the -1 padding, all prefetch targets zero) and the
+    other has one: the empty image's centre / scale / class losses are exactly 0, its objectness loss is the pure
+    background term, and losses + gradients of the whole step match the oracle."""
+    from videoyolo_amd import autograd, init
+    from oracle import targets_oracle as T
+    from oracle import yolo3_oracle as O
+    from oracle import yolo3_train_oracle as TO
+    C, B, S = 4, 2, 96
+    params = init.synthetic_params(O.param_shapes(C), seed=41)
+    x = frames(B, S, seed=12)
+    gt_boxes = np.full((B, 3, 4), -1, np.float32)
+    gt_ids = np.full((B, 3, 1), -1, np.float32)
+    gt_boxes[1, 0] = [20, 30, 70, 80]
+    gt_ids[1, 0, 0] = 2
+    tg = T.prefetch_targets(C, S, S, gt_boxes, gt_ids)
+    assert float(np.abs(tg[0][0]).sum()) == 0.0 and float(tg[0][1].sum()) > 0
+    orc = TO.OracleYolo3Train(C, dict(params))
+    ref_losses = orc.forward_train(x, gt_boxes, *tg)
+    ref_grads = orc.backward()
+    net = _net(C, params)
+    with autograd.record():
+        losses = net(x, gt_boxes, *tg)
+        autograd.backward([losses[0] + losses[1] + losses[2] + losses[3]])
+    got = [l.cpu().numpy() for l in losses]
+    for g, w in zip(got, ref_losses):
+        np.testing.assert_allclose(g, w, rtol=1e-4, atol=1e-4)
+    assert got[1][0] == 0.0 and got[2][0] == 0.0 and got[3][0] == 0.0 and got[0][0] > 0.0
+    for name, want in ref_grads.items():
+        err = np.abs(net.grad(name) - want).max() / (np.abs(want).max() + 1e-6)
+        assert err < 2e-3, (name, err)
