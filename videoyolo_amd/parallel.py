@@ -99,6 +99,9 @@ def make_host_group():
         _host_group = dist.group.WORLD
     else:
         try:
+            # single node (the launch contract): gloo over loopback — the container's hostname may not resolve
+            if os.environ.get("MASTER_ADDR", "127.0.0.1") in ("127.0.0.1", "localhost"):
+                os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
             _host_group = dist.new_group(backend="gloo")
         except Exception as e:  # no usable host interface for gloo: every rank of the node fails alike
             import warnings
