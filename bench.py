@@ -53,13 +53,14 @@ def _short_kernel_name(name):
     return name
 
 
-def _forward_tile_key(names, bm, bn):
+def _forward_tile_key(names, bm, bn, streamk=False):
     """The counter file's name of the forward, double-buffered instance of a tile:
-    conv_igemm_kernel<BM, BN, WM, WN, DGRAD = false, NS = 2>."""
+    conv_igemm_kernel<BM, BN, WM, WN, DGRAD = false, NS = 2, SK = streamk> (older builds: 5 or 6 arguments)."""
     pre = "void conv_igemm_kernel<%s, %s," % (bm, bn)
     for k in names:
         args = k[k.find("<") + 1:k.rfind(">")].replace(" ", "").split(",") if k.startswith(pre) else []
-        if len(args) >= 5 and args[4] == "false" and (len(args) == 5 or args[5] == "2"):
+        if len(args) >= 5 and args[4] == "false" and (len(args) == 5 or args[5] == "2") \
+                and (len(args) > 6 and args[6] == "true") == bool(streamk):
             return k
     return None
 
@@ -462,8 +463,9 @@ def main():
         result["roofline"]["algorithmic_bytes_per_launch_avg"] = by / n
         # HBM bytes per launch of the same kernel, measured by this run's two rocprofv3 --pmc child passes
         if traffic:
-            tile = dom.split("<")[1].rstrip(">").split("x")
-            key = _forward_tile_key(traffic, tile[0], tile[1])
+            label = dom.split("<")[1].rstrip(">")  # "<BM>x<BN>" or "<BM>x<BN>sk" (stream-K instance)
+            tile = label[:-2].split("x") if label.endswith("sk") else label.split("x")
+            key = _forward_tile_key(traffic, tile[0], tile[1], label.endswith("sk"))
             if key:
                 result["roofline"]["traffic"] = traffic[key]["hbm_bytes"]
                 result["roofline"]["traffic_detail"] = {

@@ -70,6 +70,10 @@ def test_forward_tile_key_matches_both_template_signatures():
     assert bench._forward_tile_key(names, "64", "64") == "void conv_igemm_kernel<64, 64, 2, 2, false, 2>"
     assert bench._forward_tile_key(names, "128", "64") == "void conv_igemm_kernel<128, 64, 2, 2, false>"
     assert bench._forward_tile_key(names, "128", "32") is None
+    # seven-argument names: the stream-K instance is a kernel of its own
+    names = ["void conv_igemm_kernel<128, 128, 2, 2, false, 2, true>", "void conv_igemm_kernel<128, 128, 2, 2, false, 2, false>"]
+    assert bench._forward_tile_key(names, "128", "128") == names[1]
+    assert bench._forward_tile_key(names, "128", "128", streamk=True) == names[0]
 
 
 def test_no_nested_profiler():

@@ -218,3 +218,28 @@ def test_training_step_at_416_against_the_oracle():
         assert err < 2e-3, (name, err)
     assert len(ref_grads) == 72 * 3 + 3 * 2   # (weight, gamma, beta) of the 72 cells + (weight, bias) of the 3 prediction convs
     print("416 x 416: worst gradient mismatch", worst)
+
+
+def test_stream_k_launches_equal_plain_launches():
+    """416x416 batch 16 (configs[2]'s shape) is where the forward launches of 676 / 680 / 688 tiles sit — 2.6 rounds of
+    the 256 CUs — and the library runs them as chain-preserving stream-K launches by default (conv_igemm.hip).  The same
+    seeded network and batch in two processes, VY_CONV_SK=1 and =0: the default run must really contain stream-K
+    launches, the other none, and heads, detections, losses and all 61.6 M gradients must be the same BYTES."""
+    import json
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    got = {}
+    for sk in ("1", "0"):
+        p = subprocess.run([sys.executable, os.path.join(here, "sk_digest_worker.py"), "416", "16"],
+                           env=dict(os.environ, VY_CONV_SK=sk), stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                           timeout=900, universal_newlines=True)
+        assert p.returncode == 0, p.stdout[-3000:]
+        line = [l for l in p.stdout.splitlines() if l.startswith("DIGEST ")][-1]
+        got[sk] = json.loads(line[len("DIGEST "):])
+    assert len(got["1"]["sk_launches"]) >= 10, got["1"]["sk_launches"]
+    assert got["0"]["sk_launches"] == []
+    assert got["1"]["conv_launches"] == got["0"]["conv_launches"] == 74
+    assert got["1"]["infer"] == got["0"]["infer"], "stream-K launches changed the inference results"
+    assert got["1"]["train"] == got["0"]["train"], "stream-K launches changed the training step"

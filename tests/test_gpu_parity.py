@@ -515,16 +515,19 @@ def test_small_tile_kernel_stays_bit_exact(tile):
     assert " passed" in p.stdout
 
 
-def test_stream_k_hand_off_stays_bit_exact():
+@pytest.mark.parametrize("slots,plain", [("13", False), ("24", False), ("0", True)])
+def test_stream_k_hand_off_stays_bit_exact(slots, plain):
     """The chain-preserving stream-K instances of conv_igemm.hip (a tile started by one block, its accumulators handed
-    over through a slab + flag, finished by the next block with the SAME fma chain) are off by default — measured
-    neutral-to-slower (profiles/r03_negative_results.txt) — but stay in the library: with VY_CONV_SK=1 and
-    VY_CONV_SK_SLOTS=5 every conv launch of more than 5 tiles runs on 5 blocks, so even the small shapes of this file
-    go through head / whole / tail items and the hand-off.  Heads, layer taps, odd sizes, one training step."""
+    over through a write-through slab + flag, finished by the next block with the SAME fma chain) serve the forward
+    launches whose last round of the CUs is poorly filled — none of this file's small shapes.  VY_CONV_SK_SLOTS=n runs
+    EVERY conv launch of more than n tiles (data gradients included) on n blocks: 13 = five XCD groups of two blocks and
+    three of one, 24 = three per group — whole tiles, heads, tails and the hand-off on the small shapes.  The third
+    case is the other switch position: VY_CONV_SK=0, plain launches only.  Heads, layer taps, odd sizes, one training
+    step, all against the oracle."""
     import os
     import subprocess
     import sys
-    env = dict(os.environ, VY_CONV_SK="1", VY_CONV_SK_SLOTS="5")
+    env = dict(os.environ, VY_CONV_SK="0") if plain else dict(os.environ, VY_CONV_SK="1", VY_CONV_SK_SLOTS=slots)
     here = os.path.dirname(os.path.abspath(__file__))
     p = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_parity.py"),
                         os.path.join(here, "test_gpu_train_parity.py"), "-q", "-x", "-m", "gpu", "-k",

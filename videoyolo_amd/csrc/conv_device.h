@@ -39,6 +39,15 @@ __device__ __forceinline__ float buf_load_f32(__amdgpu_buffer_rsrc_t rsrc, unsig
 __device__ __forceinline__ void buf_store_f32(float v, __amdgpu_buffer_rsrc_t rsrc, unsigned voff, int soff) {
   __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrc, voff, soff, 0);
 }
+// 16-byte write-through store / L1-bypassing load (aux 16 = sc1): the pair that hands bytes to another workgroup inside a
+// launch without an agent-scope release (an L2 write-back of the whole XCD) or acquire — MI355X_MICROARCH.md, visibility
+typedef unsigned vy_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void buf_store_f32x4_sc1(f32x4 v, __amdgpu_buffer_rsrc_t rsrc, unsigned voff) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(vy_u32x4, v), rsrc, voff, 0, 16);
+}
+__device__ __forceinline__ f32x4 buf_load_f32x4_sc1(__amdgpu_buffer_rsrc_t rsrc, unsigned voff) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 16));
+}
 #endif
 
 __device__ __forceinline__ unsigned fd_div(unsigned n, const VyFastDiv f) {

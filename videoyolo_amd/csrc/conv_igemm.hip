@@ -32,6 +32,7 @@
 // dgrad reads W as the [k][n] operand: its LDS tile is 32 k-rows of BN contiguous floats, read with
 // ds_read_b32 (32 consecutive floats per half-wave: conflict-free without a swizzle).
 #include <cstdio>
+#include <algorithm>
 #include <cstdlib>
 #include <type_traits>
 
@@ -41,12 +42,12 @@
 #include "conv_device.h"
 
 // Stream-K hand-off between the block that starts a tile and the block that finishes it (SK instances only).
-// `per` k-steps per block, `T` k-steps per tile, `tiles` tiles; partials: [grid][BM * BN] floats; flags: [grid] words,
-// zero between launches (the consumer clears the flag it waited for).
+// `tiles` tiles in the launch (the grid is smaller); partials: [grid][BM * BN] floats; flags: [grid] words, zero between
+// launches (the consumer clears the flag it waited for).
 struct SkArgs {
   float* partials;
   unsigned* flags;
-  int per, tiles;
+  int tiles;
 };
 
 // One tile of the implicit GEMM, k-steps [kb, ke): from zero or (SK) from the previous block's partial sums, to the
@@ -169,17 +170,18 @@ __device__ __forceinline__ void conv_tile(Args& a, const int tiles_n, const SkAr
 
   f32x16 acc[TM][TN];
   if constexpr (SK) {
-    // The head of a continued tile was computed by block vblk - 1 as its FIRST work item.  One lane polls its flag, then
-    // an agent-scope acquire, then the loads.  The loads are issued for EVERY item, through a buffer descriptor whose
-    // range is 0 unless this item continues a tile: out-of-range loads return 0.0f without touching memory — the
-    // accumulators have ONE definition (a branch here made hipcc keep two copies of them: 2x the registers).
+    // The head of a continued tile was computed by block vblk - 1 as its FIRST work item and stored WRITE-THROUGH (sc1).
+    // One lane polls its flag, the block's barrier, then sc1 loads (they bypass this CU's L1; no agent-scope acquire: the
+    // slab is the only memory another block of this launch writes, and every load of it is one of these).  The loads are
+    // issued for EVERY item, through a buffer descriptor whose range is 0 unless this item continues a tile:
+    // out-of-range loads return 0.0f without touching memory — the accumulators have ONE definition (a branch here
+    // made hipcc keep two copies of them: 2x the registers).
     if (load_partial && tid == 0) {
       while (__hip_atomic_load(sk.flags + (vblk - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u)
-        __builtin_amdgcn_s_sleep(8);
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_sleep(4);
     }
     if (load_partial) __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  // no instruction: keeps the loads below the poll
     const __amdgpu_buffer_rsrc_t slab = __builtin_amdgcn_make_buffer_rsrc(
         sk.partials + (size_t)(vblk > 0 ? vblk - 1 : 0) * (BM * BN), 0, load_partial ? BM * BN * 4 : 0, 0x00020000);
 #pragma unroll
@@ -187,7 +189,11 @@ __device__ __forceinline__ void conv_tile(Args& a, const int tiles_n, const SkAr
 #pragma unroll
       for (int j = 0; j < TN; ++j)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][j][r] = buf_load_f32(slab, (unsigned)((((i * TN + j) * 16 + r) * NT + tid) * 4));
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 v4 = buf_load_f32x4_sc1(slab, (unsigned)((((i * TN + j) * 4 + q) * NT + tid) * 16));
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[i][j][q * 4 + e] = v4[e];
+        }
     // (the flag is cleared for the next launch once every thread has its values: after the k-loop, see below)
   } else {
 #pragma unroll
@@ -381,22 +387,26 @@ __device__ __forceinline__ void conv_tile(Args& a, const int tiles_n, const SkAr
   if (SK && load_partial && tid == 0)  // every thread passed a k-loop barrier after loading its partial sums
     __hip_atomic_store(sk.flags + (vblk - 1), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (SK && store_partial) {
-    // head piece: the accumulators go to this block's slab; plain stores, every wave drains them, one lane publishes
-    // (agent-scope release, drained, then the flag) — MI355X_MICROARCH.md, inter-workgroup visibility
-    float* slab = sk.partials + (size_t)vblk * (BM * BN);
+    // head piece: the accumulators go to this block's slab as 16-byte write-through stores (a wave instruction covers
+    // 1 KiB of whole lines), every wave drains its own, the barrier, then one lane raises the flag — no release fence
+    // (it would write back every dirty line of the XCD's L2, the other blocks' conv outputs included: the first build
+    // did, and a hand-off cost 12 us)
+    const __amdgpu_buffer_rsrc_t slab_out =
+        __builtin_amdgcn_make_buffer_rsrc(sk.partials + (size_t)vblk * (BM * BN), 0, BM * BN * 4, 0x00020000);
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
       for (int j = 0; j < TN; ++j)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) slab[((i * TN + j) * 16 + r) * NT + tid] = acc[i][j][r];
+        for (int q = 0; q < 4; ++q) {
+          f32x4 v4;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v4[e] = acc[i][j][q * 4 + e];
+          buf_store_f32x4_sc1(v4, slab_out, (unsigned)((((i * TN + j) * 4 + q) * NT + tid) * 16));
+        }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (tid == 0) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __hip_atomic_store(sk.flags + vblk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    if (tid == 0) __hip_atomic_store(sk.flags + vblk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return;
   }
   // epilogue: affine (folded BN or bias) -> leaky -> + addend -> store (x1 or x2-replicated), through
@@ -569,35 +579,56 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_kernel(const ConvA
   if constexpr (!SK) {
     conv_tile<BM, BN, WM, WN, DGRAD, NS, SK, const ConvArgs>(a, tiles_n, sk, smem, vblk, vblk, 0, T_all, false, false);
   } else {
-    // this block's share of the k-step sequence: [it0, it1), at least one whole tile long (per >= T_all)
-    const long long total = (long long)sk.tiles * T_all;
-    const long long it0 = (long long)vblk * sk.per;
-    if (it0 >= total) return;
-    const long long it1 = it0 + sk.per < total ? it0 + sk.per : total;
-    const int first = (int)(it0 / T_all), k0 = (int)(it0 - (long long)first * T_all);
-    const int last = (int)((it1 - 1) / T_all), k1 = (int)(it1 - (long long)last * T_all);  // k1 in (0, T_all]
-    // work items in running order: [HEAD of the last tile] [whole tiles] [TAIL of the first tile]; a share inside one
-    // tile (only the final remainder with per >= T_all) is that tile's tail
-    int hb, w0, nw, tail, tk1;
-    if (first == last) {
-      hb = 0, w0 = 0, nw = 0, tail = 1, tk1 = k1;
-    } else {
-      hb = k1 < T_all ? 1 : 0;
-      w0 = k0 == 0 ? first : first + 1;
-      nw = (k1 == T_all ? last : last - 1) - w0 + 1;
-      tail = k0 > 0 ? 1 : 0;
-      tk1 = T_all;
+    // Hybrid schedule, per XCD (the blocks L, L + 8, ... and a contiguous run of the tiles, in proportion): the first
+    // D "waves" are whole tiles, block l taking tile w * gx + l of the run — what the blocks of one XCD work on at the same
+    // time are neighbouring tiles, as in a plain launch (same A rows for the n-tiles of a row, the W panel shared).  Only
+    // the last one-to-two waves' worth of tiles is cut into equal shares of k-steps.  (Equal shares of the WHOLE
+    // sequence, the first build, gave every block its own 3.5 consecutive tiles: each A tile was then fetched 3.5 times
+    // by one block instead of once for eight, and launches of ten rounds lost more than the last round returns.)
+    const int nblk = gridDim.x, L = blockIdx.x;
+    const int q = nblk >> 3, r = nblk & 7, xcd = L & 7, l = L >> 3;
+    const int gx = q + (xcd < r ? 1 : 0);                                      // blocks of this XCD
+    const int v0 = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;        // the first of them (vblk = v0 + l)
+    // (32-bit arithmetic made scalar again by hand: tiles x blocks < 2^31 is checked by the launcher; a 64-bit division
+    // is expanded into vector code with control flow and its results then count as per-lane values)
+    auto sdiv = [](unsigned n, unsigned d) { return (int)__builtin_amdgcn_readfirstlane((int)(n / d)); };
+    const int tx0 = sdiv((unsigned)sk.tiles * (unsigned)v0, (unsigned)nblk);
+    const int nloc = sdiv((unsigned)sk.tiles * (unsigned)(v0 + gx), (unsigned)nblk) - tx0;  // >= gx: tiles >= blocks
+    const int waves = sdiv((unsigned)nloc, (unsigned)gx);
+    const int D = waves > 1 ? waves - 1 : 0;
+    const int s0 = tx0 + D * gx;                                                // first tile of the stream-K region
+    const int total = (nloc - D * gx) * T_all;                                  // < 2 gx T_all
+    const int per = sdiv((unsigned)(total + gx - 1), (unsigned)gx);             // T_all <= per < 2 T_all
+    const int it0 = l * per;
+    const int it1 = it0 + per < total ? it0 + per : total;
+    // work items in running order: [D whole tiles] [HEAD of the share's last tile -> slab] [whole tiles] [TAIL of its
+    // first tile]; a share inside one tile is that tile's tail
+    int first = 0, last = 0, k0 = 0, k1 = 0, hb = 0, w0 = 0, nw = 0, tail = 0, tk1 = 0;
+    if (it0 < total) {
+      first = sdiv((unsigned)it0, (unsigned)T_all), k0 = it0 - first * T_all;
+      last = sdiv((unsigned)(it1 - 1), (unsigned)T_all), k1 = it1 - last * T_all;  // k1 in (0, T_all]
+      if (first == last) {
+        tail = 1, tk1 = k1;
+      } else {
+        hb = k1 < T_all ? 1 : 0;
+        w0 = k0 == 0 ? first : first + 1;
+        nw = (k1 == T_all ? last : last - 1) - w0 + 1;
+        tail = k0 > 0 ? 1 : 0;
+        tk1 = T_all;
+      }
     }
-    const int n_items = hb + nw + tail;
+    const int n_items = D + hb + nw + tail;
     for (int it = 0; it < n_items; ++it) {  // ONE call site: the tile body is instantiated once
       int tile, kb, ke;
       bool ld, st;
-      if (it < hb) {
-        tile = last, kb = 0, ke = k1, ld = false, st = true;
-      } else if (it < hb + nw) {
-        tile = w0 + (it - hb), kb = 0, ke = T_all, ld = false, st = false;
+      if (it < D) {
+        tile = tx0 + it * gx + l, kb = 0, ke = T_all, ld = false, st = false;
+      } else if (it < D + hb) {
+        tile = s0 + last, kb = 0, ke = k1, ld = false, st = true;
+      } else if (it < D + hb + nw) {
+        tile = s0 + w0 + (it - D - hb), kb = 0, ke = T_all, ld = false, st = false;
       } else {
-        tile = first, kb = k0, ke = tk1, ld = k0 > 0, st = tk1 < T_all;
+        tile = s0 + first, kb = k0, ke = tk1, ld = k0 > 0, st = tk1 < T_all;
       }
       // The arguments are read through the kernarg pointer, made opaque once per item: with `a` itself every field
       // (and everything derived from it) stayed live across the whole loop, the SGPRs ran out and spilled into
@@ -628,33 +659,50 @@ static int cu_count() {
   return n;
 }
 
+// `sk_query` != nullptr: nothing is launched, *sk_query tells whether the launch would be a stream-K one (the profile's label)
 template <int BM, int BN, int WM, int WN, int NS = 2>
-static hipError_t launch_cfg(const ConvArgs& a, hipStream_t s) {
+static hipError_t launch_cfg(const ConvArgs& a, hipStream_t s, bool* sk_query = nullptr) {
   const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + BN - 1) / BN;
   const long long tiles = (long long)tiles_m * tiles_n;
-  SkArgs sk = {nullptr, nullptr, 0, 0};
-  // Stream-K when the launch has more tiles than the chip holds blocks and its last round of the CUs is poorly filled:
-  // a CU works through tiles / CUs tiles, rounded UP in a plain launch (the cost model of select_cfg)
-  // OFF by default: measured on one box (profiles/r03_negative_results.txt) +0.4 % at 608x608 batch 64 (the 19x19 layers:
-  // 5.66 -> 6 rounds), -3 % at 416x416 batch 64 and -2 % in the training step — a static share per block gives up the
-  // hardware's dynamic tile scheduling, and a block with 2.7 tiles of work pays three prologues and a hand-off for them.
-  static const int sk_on = getenv("VY_CONV_SK") ? atoi(getenv("VY_CONV_SK")) : 0;
+  SkArgs sk = {nullptr, nullptr, 0};
+  // Stream-K (hybrid schedule, see the kernel) when the launch has more tiles than blocks it can keep resident and its
+  // last round of the CUs is poorly filled: a CU works through tiles / CUs tiles, rounded UP in a plain launch (the cost
+  // model of select_cfg).  ON by default for forward launches since the hand-off is write-through and the schedule keeps
+  // a plain launch's locality (profiles/r03_negative_results.txt section 2 has the two builds that lost and why):
+  // 608x608 batch 64 +0.7 %, 416x416 +0.6 %, the training forward -0.3 ms; VY_CONV_SK=0 restores plain launches.
+  static const int sk_on = getenv("VY_CONV_SK") ? atoi(getenv("VY_CONV_SK")) : 1;
   static const double sk_min_gain = getenv("VY_CONV_SK_GAIN") ? atof(getenv("VY_CONV_SK_GAIN")) : 0.03;
-  if (sk_on && a.sk_partials && a.sk_flags && NS == 2) {
+  // (data gradients: off unless VY_CONV_SK_DGRAD=1 — in the training step the weight-gradient stream runs beside them and
+  // its blocks already fill the CUs a partly filled round leaves idle; measured, stream-K there only moves the idle time)
+  static const int sk_dgrad = getenv("VY_CONV_SK_DGRAD") ? atoi(getenv("VY_CONV_SK_DGRAD")) : 0;
+  static const int sk_slots_any = getenv("VY_CONV_SK_SLOTS") ? atoi(getenv("VY_CONV_SK_SLOTS")) : 0;
+  if (sk_on && a.sk_partials && a.sk_flags && (!a.dgrad || sk_dgrad || sk_slots_any > 0)) {
     static const int res_f = resident_blocks(conv_igemm_kernel<BM, BN, WM, WN, false, NS, true>, WM * WN * 64);
     static const int res_d = resident_blocks(conv_igemm_kernel<BM, BN, WM, WN, true, NS, true>, WM * WN * 64);
     // test switch: VY_CONV_SK_SLOTS=n runs every launch of more than n tiles on n blocks (small shapes through the hand-off)
     static const int sk_slots = getenv("VY_CONV_SK_SLOTS") ? atoi(getenv("VY_CONV_SK_SLOTS")) : 0;
     const int cus = cu_count();
-    const long long G = sk_slots > 0 ? sk_slots : (long long)cus * (a.dgrad ? res_d : res_f);
+    // blocks per CU: as many as fit, but never so many that a share is shorter than one tile (a share is at most
+    // [head][whole tiles][tail]).  344 tiles (the 13x13 data gradients at batch 16): ONE block per CU with 1.34 tiles
+    // each, where the plain launch leaves 88 CUs with two tiles and 168 with one
+    const long long per_cu = std::min<long long>(a.dgrad ? res_d : res_f, tiles / cus);
+    const long long G = sk_slots > 0 ? sk_slots : (long long)cus * per_cu;
     const double rounds = (double)tiles / cus, plain = (double)((tiles + cus - 1) / cus);
-    const int T = a.ntaps * (a.Kc >> 5);
-    if (tiles > G && (sk_slots > 0 || (plain - rounds) / plain >= sk_min_gain) && G * BM * BN * 4ll <= (long long)a.sk_bytes &&
-        G <= a.sk_nflags) {
+    // predicted with select_cfg's round model: a plain launch takes plain x (alpha K + O), stream-K rounds x the same
+    // plus one hand-off (slab store, flag, slab load and a third prologue per block: 7.5 us measured on the short-K
+    // launches, which lose exactly that)
+    const double t_round = 0.0543 * (BM * BN / 16384.0) * ((double)a.ntaps * a.Kc) + (BM * BN >= 16384 ? 4.5 : BM * BN >= 8192 ? 2.6 : 1.4);
+    static const double sk_cost = getenv("VY_CONV_SK_COST") ? atof(getenv("VY_CONV_SK_COST")) : 7.5;
+    const bool pays = (plain - rounds) * t_round - sk_cost >= sk_min_gain * plain * t_round;
+    if (G > 0 && tiles > G && tiles * (G + 8) < (1ll << 31) && 2 * (G / 8 + 1) * (long long)(a.ntaps * (a.Kc >> 5)) < (1ll << 31) &&
+        (sk_slots > 0 || pays) && G * BM * BN * 4ll <= (long long)a.sk_bytes && G <= a.sk_nflags) {
+      if (sk_query) {
+        *sk_query = true;
+        return hipSuccess;
+      }
       sk.partials = a.sk_partials;
       sk.flags = a.sk_flags;
       sk.tiles = (int)tiles;
-      sk.per = (int)((tiles * T + G - 1) / G);  // >= T because tiles > G
       if (a.dgrad)
         hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, true, NS, true>), dim3((unsigned)G), dim3(WM * WN * 64), 0, s,
                            a, tiles_n, sk);
@@ -663,6 +711,10 @@ static hipError_t launch_cfg(const ConvArgs& a, hipStream_t s) {
                            a, tiles_n, sk);
       return hipGetLastError();
     }
+  }
+  if (sk_query) {
+    *sk_query = false;
+    return hipSuccess;
   }
   if (a.dgrad)
     hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, true, NS>), dim3(tiles_m * tiles_n), dim3(WM * WN * 64), 0, s,
@@ -754,6 +806,35 @@ static VyFastDiv make_fastdiv(unsigned d) {
   return f;
 }
 
+// tile choice -> template instance; `sk_query`: see launch_cfg
+static hipError_t run_cfg(const ConvArgs& a, hipStream_t s, bool* sk_query) {
+  int bm, bn;
+  select_cfg(a, &bm, &bn);
+  if (sk_query) *sk_query = false;
+  if (bm == 32) return sk_query ? hipSuccess : vy_launch_conv_s16(a, bm, bn, s);
+  // experiment switch: VY_CONV_S16=1 sends a forced tile (VY_CONV_FORCE) through the 16x16x4 kernel where it has the instance
+  static const int s16_forced = getenv("VY_CONV_S16") ? atoi(getenv("VY_CONV_S16")) : 0;
+  if (s16_forced && !sk_query && !a.dgrad && (bm % 32 == 0) && (bn == 64 || bn == 96)) {
+    const hipError_t e = vy_launch_conv_s16(a, bm, bn, s);
+    if (e != hipErrorInvalidValue) return e;
+  }
+  if (bn == 32) return launch_cfg<128, 32, 4, 1>(a, s, sk_query);
+  if (bm == 128 && bn == 64) return launch_cfg<128, 64, 2, 2>(a, s, sk_query);
+  if (bm == 64) {
+    // few blocks (at most two per CU) and a k-loop long enough to fill it: the four-stage pipeline
+    static const int deep = getenv("VY_CONV_DEEP") ? atoi(getenv("VY_CONV_DEEP")) : 512;
+    const long long nb = (long long)((a.M + 63) / 64) * ((a.N + 63) / 64);
+    if (nb <= deep && a.ntaps * (a.Kc >> 5) >= 8) return launch_cfg<64, 64, 2, 2, 4>(a, s, sk_query);
+    return launch_cfg<64, 64, 2, 2>(a, s, sk_query);
+  }
+  return launch_cfg<128, 128, 2, 2>(a, s, sk_query);
+}
+
+bool vy_conv_streamk(const ConvArgs& a) {
+  bool sk = false;
+  return run_cfg(a, nullptr, &sk) == hipSuccess && sk;
+}
+
 hipError_t vy_launch_conv_igemm(const ConvArgs& a_in, hipStream_t s) {
   ConvArgs a = a_in;
   if (a.LW < 1 || a.LH < 1) return hipErrorInvalidValue;
@@ -773,23 +854,5 @@ hipError_t vy_launch_conv_igemm(const ConvArgs& a_in, hipStream_t s) {
     const bool bn_cell = a.scale && a.shift && a.leaky, plain = !a.scale && !a.leaky;
     if (!((bn_cell && (a.ups != 2 || !a.res)) || (plain && a.ups != 2))) return hipErrorInvalidValue;
   }
-  int bm, bn;
-  select_cfg(a, &bm, &bn);
-  if (bm == 32) return vy_launch_conv_s16(a, bm, bn, s);
-  // experiment switch: VY_CONV_S16=1 sends a forced tile (VY_CONV_FORCE) through the 16x16x4 kernel where it has the instance
-  static const int s16_forced = getenv("VY_CONV_S16") ? atoi(getenv("VY_CONV_S16")) : 0;
-  if (s16_forced && !a.dgrad && (bm % 32 == 0) && (bn == 64 || bn == 96)) {
-    const hipError_t e = vy_launch_conv_s16(a, bm, bn, s);
-    if (e != hipErrorInvalidValue) return e;
-  }
-  if (bn == 32) return launch_cfg<128, 32, 4, 1>(a, s);
-  if (bm == 128 && bn == 64) return launch_cfg<128, 64, 2, 2>(a, s);
-  if (bm == 64) {
-    // few blocks (at most two per CU) and a k-loop long enough to fill it: the four-stage pipeline
-    static const int deep = getenv("VY_CONV_DEEP") ? atoi(getenv("VY_CONV_DEEP")) : 512;
-    const long long nb = (long long)((a.M + 63) / 64) * ((a.N + 63) / 64);
-    if (nb <= deep && a.ntaps * (a.Kc >> 5) >= 8) return launch_cfg<64, 64, 2, 2, 4>(a, s);
-    return launch_cfg<64, 64, 2, 2>(a, s);
-  }
-  return launch_cfg<128, 128, 2, 2>(a, s);
+  return run_cfg(a, s, nullptr);
 }

@@ -61,6 +61,7 @@ hipError_t vy_launch_conv_igemm(const ConvArgs& a, hipStream_t s);
 hipError_t vy_launch_conv_s16(const ConvArgs& a, int bm, int bn, hipStream_t s);
 int vy_conv_tiles_m(const ConvArgs& a);
 void vy_conv_cfg(const ConvArgs& a, int* bm, int* bn);  // block tile the launch will use
+bool vy_conv_streamk(const ConvArgs& a);                  // ... and whether it will be a stream-K launch (label "<BM>x<BN>sk")
 
 // stem: 3x3 stride-1 conv from the caller's NCHW image (Cin = 3) into a plane, fused affine+leaky.
 struct StemArgs {

@@ -483,7 +483,7 @@ struct vy_net {
         int bm, bn;
         vy_conv_cfg(a, &bm, &bn);
         char nm[96];
-        snprintf(nm, sizeof nm, "%s|%dx%d", c.name.c_str(), bm, bn);
+        snprintf(nm, sizeof nm, "%s|%dx%d%s", c.name.c_str(), bm, bn, vy_conv_streamk(a) ? "sk" : "");
         hook(nm, fl, by, true);
         HIP_TRY(vy_launch_conv_igemm(a, s));
         hook(nm, fl, by, false);
