@@ -461,6 +461,15 @@ def main():
             "by_kernel_ms": {k: round(a[1], 4) for k, a in agg.items()},
         }
         result["roofline"]["algorithmic_bytes_per_launch_avg"] = by / n
+        # the same tile's launches that ran as chain-preserving stream-K are a kernel of their own for rocprofv3
+        # (conv_igemm_kernel<..., SK = true>): reported beside the dominant one, same definition of `achieved`
+        twin = dom[:-3] + ">" if dom.endswith("sk>") else dom[:-1] + "sk>"
+        if twin in agg:
+            tn, tms, tfl, tby = agg[twin]
+            result["roofline"]["same_tile_other_instance"] = {
+                "kernel": twin, "launches_per_step": tn, "avg_launch_ms": tms / tn,
+                "achieved": tfl / (tms * 1e-3) / 1e12, "frac": tfl / (tms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+                "both_instances_frac": (fl + tfl) / ((ms + tms) * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS}
         # HBM bytes per launch of the same kernel, measured by this run's two rocprofv3 --pmc child passes
         if traffic:
             label = dom.split("<")[1].rstrip(">")  # "<BM>x<BN>" or "<BM>x<BN>sk" (stream-K instance)

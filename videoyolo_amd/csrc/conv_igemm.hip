@@ -659,41 +659,90 @@ static int cu_count() {
   return n;
 }
 
+// ---- the launch cost model, shared by the tile choice (select_cfg) and the stream-K decision (launch_cfg) ----
+// Measured on the MI355X (tools/train_layers.sh with VY_CONV_FORCE, 416x416 batch 16 and 608x608 batch 64): a launch of T
+// tiles takes ceil(T / 256) x (alpha(tile) x K + O(tile)) — every CU works through its share of the tiles at a rate that
+// does not depend on how many blocks it holds (2 resident 128x128 blocks, 3 of 128x64, 4 of 64x64), and what is lost is
+// the last, partly filled round of the 256 CUs.  Fitted per tile, in microseconds: alpha = 0.0543 / 0.0273 / 0.0145 per
+// unit of K, fixed part O = 4.5 / 2.6 / 1.4 (prologue tables + the epilogue of 64 / 32 / 16 accumulator registers per
+// lane).  A stream-K launch (hybrid schedule, see the kernel) takes T / 256 rounds, not rounded up, plus one hand-off:
+// 7.5 us fitted on the short-K launches, which lose exactly that.
+struct TileModel {
+  int bm, bn;
+  double alpha, fixed;
+  int resident;  // blocks per CU
+};
+static const TileModel kTileModels[3] = {{128, 128, 0.0543, 4.5, 2}, {128, 64, 0.0273, 2.6, 3}, {64, 64, 0.0145, 1.4, 4}};
+static const TileModel* tile_model(int bm, int bn) {
+  for (const TileModel& t : kTileModels)
+    if (t.bm == bm && t.bn == bn) return &t;
+  return nullptr;
+}
+struct SkSwitches {
+  int on, dgrad, slots;
+  double min_gain, cost;
+};
+// VY_CONV_SK=0: plain launches only.  VY_CONV_SK_DGRAD=1: data gradients too (off: in the training step the weight-
+// gradient stream runs beside them and its blocks already fill the CUs a partly filled round leaves idle; measured,
+// stream-K there only moves the idle time).  VY_CONV_SK_SLOTS=n (tests): EVERY launch of more than n tiles on n blocks.
+// VY_CONV_SK_GAIN / VY_CONV_SK_COST: the criterion's threshold (3 % of the plain launch) and hand-off cost (7.5 us).
+static const SkSwitches& sk_switches() {
+  static const SkSwitches s = {getenv("VY_CONV_SK") ? atoi(getenv("VY_CONV_SK")) : 1,
+                               getenv("VY_CONV_SK_DGRAD") ? atoi(getenv("VY_CONV_SK_DGRAD")) : 0,
+                               getenv("VY_CONV_SK_SLOTS") ? atoi(getenv("VY_CONV_SK_SLOTS")) : 0,
+                               getenv("VY_CONV_SK_GAIN") ? atof(getenv("VY_CONV_SK_GAIN")) : 0.03,
+                               getenv("VY_CONV_SK_COST") ? atof(getenv("VY_CONV_SK_COST")) : 7.5};
+  return s;
+}
+static bool sk_allowed(const ConvArgs& a) {
+  const SkSwitches& w = sk_switches();
+  return w.on && a.sk_partials && a.sk_flags && (!a.dgrad || w.dgrad || w.slots > 0);
+}
+// predicted time of the launch on tile t (microseconds); *use_sk: as a stream-K launch
+static double predict_launch(const ConvArgs& a, const TileModel& t, bool* use_sk) {
+  const long long tiles = (long long)((a.M + t.bm - 1) / t.bm) * ((a.N + t.bn - 1) / t.bn);
+  const double t_round = t.alpha * ((double)a.ntaps * a.Kc) + t.fixed;
+  const bool small = t.bm * t.bn < 128 * 128;
+  double t_plain = (double)((tiles + 255) / 256) * t_round;
+  if (tiles < 256 && small) t_plain *= 1.12;  // lone small blocks (one wave per SIMD) run 10-19 % over the model
+  *use_sk = false;
+  if (sk_allowed(a) && tiles > 256) {
+    const long long per_cu = std::min<long long>(t.resident, tiles / 256);  // a share is at least one tile
+    if (tiles > 256 * per_cu) {
+      double t_sk = (double)tiles / 256.0 * t_round;
+      if (per_cu == 1 && small) t_sk *= 1.12;
+      t_sk += sk_switches().cost;
+      if (t_plain - t_sk >= sk_switches().min_gain * t_plain) {
+        *use_sk = true;
+        return t_sk;
+      }
+    }
+  }
+  return t_plain;
+}
+
 // `sk_query` != nullptr: nothing is launched, *sk_query tells whether the launch would be a stream-K one (the profile's label)
 template <int BM, int BN, int WM, int WN, int NS = 2>
 static hipError_t launch_cfg(const ConvArgs& a, hipStream_t s, bool* sk_query = nullptr) {
   const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + BN - 1) / BN;
   const long long tiles = (long long)tiles_m * tiles_n;
   SkArgs sk = {nullptr, nullptr, 0};
-  // Stream-K (hybrid schedule, see the kernel) when the launch has more tiles than blocks it can keep resident and its
-  // last round of the CUs is poorly filled: a CU works through tiles / CUs tiles, rounded UP in a plain launch (the cost
-  // model of select_cfg).  ON by default for forward launches since the hand-off is write-through and the schedule keeps
-  // a plain launch's locality (profiles/r03_negative_results.txt section 2 has the two builds that lost and why):
-  // 608x608 batch 64 +0.7 %, 416x416 +0.6 %, the training forward -0.3 ms; VY_CONV_SK=0 restores plain launches.
-  static const int sk_on = getenv("VY_CONV_SK") ? atoi(getenv("VY_CONV_SK")) : 1;
-  static const double sk_min_gain = getenv("VY_CONV_SK_GAIN") ? atof(getenv("VY_CONV_SK_GAIN")) : 0.03;
-  // (data gradients: off unless VY_CONV_SK_DGRAD=1 — in the training step the weight-gradient stream runs beside them and
-  // its blocks already fill the CUs a partly filled round leaves idle; measured, stream-K there only moves the idle time)
-  static const int sk_dgrad = getenv("VY_CONV_SK_DGRAD") ? atoi(getenv("VY_CONV_SK_DGRAD")) : 0;
-  static const int sk_slots_any = getenv("VY_CONV_SK_SLOTS") ? atoi(getenv("VY_CONV_SK_SLOTS")) : 0;
-  if (sk_on && a.sk_partials && a.sk_flags && (!a.dgrad || sk_dgrad || sk_slots_any > 0)) {
+  // Stream-K when the cost model says it pays (predict_launch): the launches whose last round of the CUs is poorly
+  // filled.  ON by default for forward launches since the hand-off is write-through and the schedule keeps a plain
+  // launch's locality (profiles/r03_negative_results.txt section 2 has the two builds that lost and why): 608x608
+  // batch 64 +0.7 %, 416x416 +0.6 %, the training forward -0.3 ms; VY_CONV_SK=0 restores plain launches.
+  if (sk_allowed(a)) {
     static const int res_f = resident_blocks(conv_igemm_kernel<BM, BN, WM, WN, false, NS, true>, WM * WN * 64);
     static const int res_d = resident_blocks(conv_igemm_kernel<BM, BN, WM, WN, true, NS, true>, WM * WN * 64);
-    // test switch: VY_CONV_SK_SLOTS=n runs every launch of more than n tiles on n blocks (small shapes through the hand-off)
-    static const int sk_slots = getenv("VY_CONV_SK_SLOTS") ? atoi(getenv("VY_CONV_SK_SLOTS")) : 0;
+    const int sk_slots = sk_switches().slots;
     const int cus = cu_count();
     // blocks per CU: as many as fit, but never so many that a share is shorter than one tile (a share is at most
-    // [head][whole tiles][tail]).  344 tiles (the 13x13 data gradients at batch 16): ONE block per CU with 1.34 tiles
-    // each, where the plain launch leaves 88 CUs with two tiles and 168 with one
+    // [head][whole tiles][tail]).  344 tiles (the 13x13 maps at batch 16): ONE block per CU with 1.34 tiles each, where
+    // the plain launch leaves 88 CUs with two tiles and 168 with one
     const long long per_cu = std::min<long long>(a.dgrad ? res_d : res_f, tiles / cus);
     const long long G = sk_slots > 0 ? sk_slots : (long long)cus * per_cu;
-    const double rounds = (double)tiles / cus, plain = (double)((tiles + cus - 1) / cus);
-    // predicted with select_cfg's round model: a plain launch takes plain x (alpha K + O), stream-K rounds x the same
-    // plus one hand-off (slab store, flag, slab load and a third prologue per block: 7.5 us measured on the short-K
-    // launches, which lose exactly that)
-    const double t_round = 0.0543 * (BM * BN / 16384.0) * ((double)a.ntaps * a.Kc) + (BM * BN >= 16384 ? 4.5 : BM * BN >= 8192 ? 2.6 : 1.4);
-    static const double sk_cost = getenv("VY_CONV_SK_COST") ? atof(getenv("VY_CONV_SK_COST")) : 7.5;
-    const bool pays = (plain - rounds) * t_round - sk_cost >= sk_min_gain * plain * t_round;
+    bool pays = false;
+    if (const TileModel* tm = tile_model(BM, BN)) predict_launch(a, *tm, &pays);
     if (G > 0 && tiles > G && tiles * (G + 8) < (1ll << 31) && 2 * (G / 8 + 1) * (long long)(a.ntaps * (a.Kc >> 5)) < (1ll << 31) &&
         (sk_slots > 0 || pays) && G * BM * BN * 4ll <= (long long)a.sk_bytes && G <= a.sk_nflags) {
       if (sk_query) {
@@ -745,25 +794,18 @@ static void select_cfg(const ConvArgs& a, int* bm, int* bn) {
     *bn = 32;
     return;
   }
-  struct Cand {
-    int bm, bn;
-    double alpha, fixed;
-  };
-  const Cand cands[3] = {{128, 128, 0.0543, 4.5}, {128, 64, 0.0273, 2.6}, {64, 64, 0.0145, 1.4}};
-  const double K = (double)a.ntaps * a.Kc;
   double best = 1e300;
-  for (const Cand& c : cands) {
+  for (const TileModel& c : kTileModels) {
     if (c.bn == 128 && a.N <= 64) continue;
-    const long long nb = blocks(c.bm, c.bn);
-    const long long rounds = (nb + 255) / 256;
-    double t = (double)rounds * (c.alpha * K + c.fixed);
-    if (nb < 256 && c.bm * c.bn < 128 * 128) t *= 1.12;  // lone small blocks (one wave per SIMD) run 10-19 % over the model
+    bool sk;
+    const double t = predict_launch(a, c, &sk);  // as a plain or a stream-K launch, whichever the launcher will pick
     if (t < best * 0.995) {
       best = t;
       *bm = c.bm;
       *bn = c.bn;
     }
   }
+  const double K = (double)a.ntaps * a.Kc;
   // 16x16 wave tiles (conv_small.hip; block tile 32 x {32, 64}): OFF by default.  Measured on the MI355X (round 3,
   // profiles/r03_negative_results.txt): bit-exact, but 1.9 - 2.0x SLOWER than the 64x64 tile on the batch-1 3x3 layers it
   // was built for (76x76: 78-85 vs 42 us, 38x38: 85-88 vs 43, 19x19: 98-128 vs 77) — a 32-channel sub-step of a 32x32
