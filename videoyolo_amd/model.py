@@ -150,8 +150,9 @@ class YOLOV3(object):
         self._graphs = {}
         self._use_graphs = os.environ.get("VY_HIP_GRAPHS", "1") != "0"
         # batches at least this large run as two half-batches on two streams (two hardware queues);
-        # 0 (default) disables: measured 838 vs 828 frames/s at 608x608 batch 64 (+1.2 %, +2.6 % at
-        # 416x416) — launch tails are mostly not idle — for a second workspace binding, so it is opt-in
+        # 0 (default) disables.  Round 1: 838 vs 828 frames/s at 608x608 batch 64 (+1.2 %, +2.6 % at 416x416), the
+        # second stream filling partly filled rounds.  Round 3, with those launches running as stream-K: 972 vs 984
+        # (-1.2 %), 1990 vs 2049 at 416x416 (tools/ab_two_stream.sh) — the holes are gone, the halves only cost
         self.two_stream_batch = int(os.environ.get("VY_TWO_STREAM_BATCH", "0"))
         self._twin = None
         _lib.check(self._lib.vy_net_set_nms(self._h, nms_thresh, nms_topk, post_nms))
