@@ -2,7 +2,10 @@
 batch; prints which inference launches ran as stream-K and SHA-256 digests of (a) the three raw heads + the detections
 and (b) the four losses + all gradients of one recorded training step.  VY_CONV_SK is read once per process by the
 library, so the two switch positions need two processes.
-usage: python sk_digest_worker.py SIZE BATCH"""
+With a third argument "graph" the net is hybridized BEFORE its first forward — the capture is then the first time the
+library sees these launches (its once-per-instance occupancy queries run inside the capture) — and only the inference
+digest is produced, from two replays.
+usage: python sk_digest_worker.py SIZE BATCH [graph]"""
 import hashlib
 import json
 import os
@@ -24,6 +27,13 @@ net.collect_params().reset_ctx("cuda:0")
 net.set_nms(0.45, 400, 100)
 x = torch.as_tensor(frames(B, S, seed=3)).cuda()
 
+graph = len(sys.argv) > 3 and sys.argv[3] == "graph"
+if graph:
+    net.hybridize()
+    first = [t.clone() for t in net(x, return_index=True)]   # capture + first replay
+    assert len(net._graphs) == 1
+    again = net(x, return_index=True)
+    assert all(torch.equal(a, b) for a, b in zip(first, again)), "graph replays differ"
 labels = [name for name, _, _, _ in net.profile(x)]
 h = hashlib.sha256()
 for t in net(x, return_index=True):
@@ -33,6 +43,9 @@ for i in range(3):
 out = {"sk_launches": [n for n in labels if n.endswith("sk")], "conv_launches": sum("|" in n for n in labels),
        "infer": h.hexdigest()}
 
+if graph:
+    print("DIGEST " + json.dumps(out))
+    sys.exit(0)
 gt, gid = targets.synthetic_gt(B, S, C, m=8, seed=1)
 tg = targets.YOLOV3PrefetchTargetGenerator(C)(S, S, gt, gid, device="cuda:0")
 with autograd.record():

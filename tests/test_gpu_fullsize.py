@@ -231,10 +231,10 @@ def test_stream_k_launches_equal_plain_launches():
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
     got = {}
-    for sk in ("1", "0"):
-        p = subprocess.run([sys.executable, os.path.join(here, "sk_digest_worker.py"), "416", "16"],
-                           env=dict(os.environ, VY_CONV_SK=sk), stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
-                           timeout=900, universal_newlines=True)
+    for sk, extra in (("1", []), ("0", []), ("graph", ["graph"])):
+        p = subprocess.run([sys.executable, os.path.join(here, "sk_digest_worker.py"), "416", "16"] + extra,
+                           env=dict(os.environ, VY_CONV_SK="0" if sk == "0" else "1"), stdout=subprocess.PIPE,
+                           stderr=subprocess.STDOUT, timeout=900, universal_newlines=True)
         assert p.returncode == 0, p.stdout[-3000:]
         line = [l for l in p.stdout.splitlines() if l.startswith("DIGEST ")][-1]
         got[sk] = json.loads(line[len("DIGEST "):])
@@ -243,3 +243,6 @@ def test_stream_k_launches_equal_plain_launches():
     assert got["1"]["conv_launches"] == got["0"]["conv_launches"] == 74
     assert got["1"]["infer"] == got["0"]["infer"], "stream-K launches changed the inference results"
     assert got["1"]["train"] == got["0"]["train"], "stream-K launches changed the training step"
+    # the same launches captured into a hipGraph as the very first thing the process does with them, replayed twice
+    assert got["graph"]["sk_launches"] == got["1"]["sk_launches"]
+    assert got["graph"]["infer"] == got["1"]["infer"], "hipGraph replay of stream-K launches differs from eager"
