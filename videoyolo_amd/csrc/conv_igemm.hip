@@ -409,6 +409,20 @@ __device__ __forceinline__ void conv_tile(Args& a, const int tiles_n, const SkAr
     if (tid == 0) __hip_atomic_store(sk.flags + vblk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return;
   }
+#if defined(VY_CONV_ABLATE) && (VY_CONV_ABLATE & 1)  // tools/probe/conv_tile_trace.hip only: what would a free epilogue buy?
+  {
+    float s_ = 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s_ += acc[i][j][r];
+    if (s_ == 12345.678f) a.out[tid] = s_;
+    VY_TRACE(3)
+    return;
+  }
+#endif
   // epilogue: affine (folded BN or bias) -> leaky -> + addend -> store (x1 or x2-replicated), through
   // buffer descriptors based at the tile's first pixel and column (see the row tables above)
   constexpr int kRsrcFlags = 0x00020000;  // raw dword buffer, gfx9 data format 32
