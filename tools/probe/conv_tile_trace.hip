@@ -160,6 +160,14 @@ int main(int argc, char** argv) {
     printf("  %-8s n=%6zu mean %7.2f  p10 %7.2f  p50 %7.2f  p90 %7.2f  max %7.2f us\n", name, v.size(), s / v.size(),
            v[v.size() / 10], v[v.size() / 2], v[v.size() * 9 / 10], v.back());
   };
+  // where the dispatcher puts the first blocks of XCD 0 (blockIdx 0, 8, 16, ...): CU id and start time
+  printf("  first blocks of XCD 0: (block, cu, start us)");
+  for (long long b = 0; b < tiles && b < 8 * 80; b += 8) {
+    const unsigned long long* r = &tr[(size_t)b * 8];
+    if (!r[3]) continue;
+    printf(" (%lld,%d,%.1f)", b, (int)((r[4] >> 8) & 0xff), (r[0] - tmin) * 0.01);
+  }
+  printf("\n");
   stat("prologue", pro);
   stat("k-loop", kloop);
   stat("epilogue", epi);
