@@ -5,7 +5,8 @@ library, so the two switch positions need two processes.
 With a third argument "graph" the net is hybridized BEFORE its first forward — the capture is then the first time the
 library sees these launches (its once-per-instance occupancy queries run inside the capture) — and only the inference
 digest is produced, from two replays.
-usage: python sk_digest_worker.py SIZE BATCH [graph]"""
+"infer" as the third argument stops after the inference digest (tools/sk_sweep.py).
+usage: python sk_digest_worker.py SIZE BATCH [graph|infer]"""
 import hashlib
 import json
 import os
@@ -43,7 +44,7 @@ for i in range(3):
 out = {"sk_launches": [n for n in labels if n.endswith("sk")], "conv_launches": sum("|" in n for n in labels),
        "infer": h.hexdigest()}
 
-if graph:
+if graph or (len(sys.argv) > 3 and sys.argv[3] == "infer"):
     print("DIGEST " + json.dumps(out))
     sys.exit(0)
 gt, gid = targets.synthetic_gt(B, S, C, m=8, seed=1)
