@@ -40,6 +40,7 @@
 #include "../../include/vy_math.h"
 
 #include "conv_device.h"
+#include "sk_schedule.h"
 
 // Stream-K hand-off between the block that starts a tile and the block that finishes it (SK instances only).
 // `tiles` tiles in the launch (the grid is smaller); partials: [grid][BM * BN] floats; flags: [grid] words, zero between
@@ -170,7 +171,7 @@ __device__ __forceinline__ void conv_tile(Args& a, const int tiles_n, const SkAr
 
   f32x16 acc[TM][TN];
   if constexpr (SK) {
-    // The head of a continued tile was computed by block vblk - 1 as its FIRST work item and stored WRITE-THROUGH (sc1).
+    // The head of a continued tile was computed by block vblk - 1 (right after its whole-tile waves) and stored WRITE-THROUGH (sc1).
     // One lane polls its flag, the block's barrier, then sc1 loads (they bypass this CU's L1; no agent-scope acquire: the
     // slab is the only memory another block of this launch writes, and every load of it is one of these).  The loads are
     // issued for EVERY item, through a buffer descriptor whose range is 0 unless this item continues a tile:
@@ -593,57 +594,15 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_kernel(const ConvA
   if constexpr (!SK) {
     conv_tile<BM, BN, WM, WN, DGRAD, NS, SK, const ConvArgs>(a, tiles_n, sk, smem, vblk, vblk, 0, T_all, false, false);
   } else {
-    // Hybrid schedule, per XCD (the blocks L, L + 8, ... and a contiguous run of the tiles, in proportion): the first
-    // D "waves" are whole tiles, block l taking tile w * gx + l of the run — what the blocks of one XCD work on at the same
-    // time are neighbouring tiles, as in a plain launch (same A rows for the n-tiles of a row, the W panel shared).  Only
-    // the last one-to-two waves' worth of tiles is cut into equal shares of k-steps.  (Equal shares of the WHOLE
-    // sequence, the first build, gave every block its own 3.5 consecutive tiles: each A tile was then fetched 3.5 times
-    // by one block instead of once for eight, and launches of ten rounds lost more than the last round returns.)
-    const int nblk = gridDim.x, L = blockIdx.x;
-    const int q = nblk >> 3, r = nblk & 7, xcd = L & 7, l = L >> 3;
-    const int gx = q + (xcd < r ? 1 : 0);                                      // blocks of this XCD
-    const int v0 = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;        // the first of them (vblk = v0 + l)
+    // which k-steps of which tiles: sk_schedule.h (shared with the host-side checker of the CPU test suite).
     // (32-bit arithmetic made scalar again by hand: tiles x blocks < 2^31 is checked by the launcher; a 64-bit division
     // is expanded into vector code with control flow and its results then count as per-lane values)
     auto sdiv = [](unsigned n, unsigned d) { return (int)__builtin_amdgcn_readfirstlane((int)(n / d)); };
-    const int tx0 = sdiv((unsigned)sk.tiles * (unsigned)v0, (unsigned)nblk);
-    const int nloc = sdiv((unsigned)sk.tiles * (unsigned)(v0 + gx), (unsigned)nblk) - tx0;  // >= gx: tiles >= blocks
-    const int waves = sdiv((unsigned)nloc, (unsigned)gx);
-    const int D = waves > 1 ? waves - 1 : 0;
-    const int s0 = tx0 + D * gx;                                                // first tile of the stream-K region
-    const int total = (nloc - D * gx) * T_all;                                  // < 2 gx T_all
-    const int per = sdiv((unsigned)(total + gx - 1), (unsigned)gx);             // T_all <= per < 2 T_all
-    const int it0 = l * per;
-    const int it1 = it0 + per < total ? it0 + per : total;
-    // work items in running order: [D whole tiles] [HEAD of the share's last tile -> slab] [whole tiles] [TAIL of its
-    // first tile]; a share inside one tile is that tile's tail
-    int first = 0, last = 0, k0 = 0, k1 = 0, hb = 0, w0 = 0, nw = 0, tail = 0, tk1 = 0;
-    if (it0 < total) {
-      first = sdiv((unsigned)it0, (unsigned)T_all), k0 = it0 - first * T_all;
-      last = sdiv((unsigned)(it1 - 1), (unsigned)T_all), k1 = it1 - last * T_all;  // k1 in (0, T_all]
-      if (first == last) {
-        tail = 1, tk1 = k1;
-      } else {
-        hb = k1 < T_all ? 1 : 0;
-        w0 = k0 == 0 ? first : first + 1;
-        nw = (k1 == T_all ? last : last - 1) - w0 + 1;
-        tail = k0 > 0 ? 1 : 0;
-        tk1 = T_all;
-      }
-    }
-    const int n_items = D + hb + nw + tail;
-    for (int it = 0; it < n_items; ++it) {  // ONE call site: the tile body is instantiated once
-      int tile, kb, ke;
-      bool ld, st;
-      if (it < D) {
-        tile = tx0 + it * gx + l, kb = 0, ke = T_all, ld = false, st = false;
-      } else if (it < D + hb) {
-        tile = s0 + last, kb = 0, ke = k1, ld = false, st = true;
-      } else if (it < D + hb + nw) {
-        tile = s0 + w0 + (it - D - hb), kb = 0, ke = T_all, ld = false, st = false;
-      } else {
-        tile = s0 + first, kb = k0, ke = tk1, ld = k0 > 0, st = tk1 < T_all;
-      }
+    const SkSchedule sch = sk_schedule((int)gridDim.x, (int)blockIdx.x, sk.tiles, T_all, sdiv);
+    for (int it = 0; it < sch.n_items; ++it) {  // ONE call site: the tile body is instantiated once
+      const SkItem w = sk_item(sch, it, T_all);
+      const int tile = w.tile, kb = w.kb, ke = w.ke;
+      const bool ld = w.load_partial, st = w.store_partial;
       // The arguments are read through the kernarg pointer, made opaque once per item: with `a` itself every field
       // (and everything derived from it) stayed live across the whole loop, the SGPRs ran out and spilled into
       // vector registers (78 -> 151 VGPRs for the 64x64 tile, scratch for 128x128, an occupancy step lost)
