@@ -1,0 +1,45 @@
+// Host-side check of videoyolo_amd/csrc/conv_cost_model.h (g++, CPU test suite): the (block tile, stream-K?) decisions for
+// the conv shapes of BASELINE.json's workloads, as measured and adopted on the MI355X in round 3, and the model's
+// structural properties.  A change of a constant that moves one of these decisions has to be re-measured, not slipped in.
+// Output: one line per shape "M N K -> BMxBN[sk]"; exit code 1 on a violated property.
+#include <cstdio>
+
+#include "../videoyolo_amd/csrc/conv_cost_model.h"
+
+int main() {
+  const VySkPolicy on = {true, 0.03, 7.5}, off = {false, 0.03, 7.5};
+  struct Shape {
+    long long M;
+    int N;
+    double K;
+  };
+  // 608x608 batch 64 (configs[1]), 416x416 batch 16 forward (configs[2]), 608x608 batch 1
+  const Shape shapes[] = {
+      {64ll * 304 * 304, 64, 288},  {64ll * 304 * 304, 32, 64},   {64ll * 152 * 152, 128, 576}, {64ll * 152 * 152, 64, 128},
+      {64ll * 76 * 76, 256, 1152},  {64ll * 76 * 76, 128, 256},   {64ll * 38 * 38, 512, 2304},  {64ll * 38 * 38, 256, 512},
+      {64ll * 19 * 19, 1024, 4608}, {64ll * 19 * 19, 512, 1024},  {64ll * 19 * 19, 75, 1024},   {16ll * 52 * 52, 256, 1152},
+      {16ll * 26 * 26, 512, 2304},  {16ll * 13 * 13, 1024, 4608}, {16ll * 13 * 13, 512, 1024},  {16ll * 52 * 52, 128, 256},
+      {1ll * 76 * 76, 256, 1152},   {1ll * 19 * 19, 1024, 4608},
+  };
+  for (const Shape& s : shapes) {
+    int bm = 0, bn = 0, bm0 = 0, bn0 = 0;
+    bool sk = false, sk0 = true;
+    const double t = vy_select_tile(s.M, s.N, s.K, on, &bm, &bn, &sk);
+    const double t0 = vy_select_tile(s.M, s.N, s.K, off, &bm0, &bn0, &sk0);
+    printf("%lld %d %.0f -> %dx%d%s\n", s.M, s.N, s.K, bm, bn, sk ? "sk" : "");
+    if (sk0) return fprintf(stderr, "stream-K chosen although not allowed\n"), 1;
+    if (t > t0 * (1.0 + 1e-12)) return fprintf(stderr, "allowing stream-K made the prediction worse\n"), 1;
+    if (s.N <= 32 && !(bm == 128 && bn == 32 && !sk)) return fprintf(stderr, "N <= 32 must use the 128x32 tile\n"), 1;
+    if (s.N > 32 && !vy_tile_model(bm, bn)) return fprintf(stderr, "tile without a model\n"), 1;
+    if (sk) {  // a stream-K launch has more tiles than blocks, and its predicted saving clears the threshold
+      const VyTileModel* m = vy_tile_model(bm, bn);
+      const long long tiles = ((s.M + bm - 1) / bm) * ((s.N + bn - 1) / bn);
+      const long long per_cu = tiles / 256 < m->resident ? tiles / 256 : m->resident;
+      bool dummy;
+      const double plain = vy_predict_launch(s.M, s.N, s.K, *m, off, &dummy);
+      if (per_cu < 1 || tiles <= 256 * per_cu) return fprintf(stderr, "stream-K launch without a cut tile\n"), 1;
+      if (plain - t < 0.03 * plain - 1e-9) return fprintf(stderr, "stream-K below its threshold\n"), 1;
+    }
+  }
+  return 0;
+}

@@ -1,0 +1,84 @@
+// conv_cost_model.h — the launch cost model of the implicit-GEMM conv: which block tile a launch uses and whether it runs
+// as a chain-preserving stream-K launch.  Host-only, plain C++ (no HIP types): conv_igemm.hip includes it, and so does
+// tests/conv_cost_model_check.cpp, which the CPU test suite compiles with g++ to pin the decisions for BASELINE's shapes.
+//
+// Measured on the MI355X (tools/train_layers.sh with VY_CONV_FORCE, 416x416 batch 16 and 608x608 batch 64): a launch of T
+// tiles takes ceil(T / 256) x (alpha(tile) x K + O(tile)) — every CU works through its share of the tiles at a rate that
+// does not depend on how many blocks it holds (2 resident 128x128 blocks, 3 of 128x64, 4 of 64x64), and what is lost is
+// the last, partly filled round of the 256 CUs.  Fitted per tile, in microseconds (refitted after the k-loop lost its
+// vector instructions): alpha = 0.0543 / 0.0273 / 0.0145 per unit of K (the 128x64 tile costs exactly half of 128x128),
+// fixed part O = 4.5 / 2.6 / 1.4 (prologue tables + the epilogue of 64 / 32 / 16 accumulator registers per lane):
+// short-K 1x1 layers prefer the small tiles, long-K 3x3 layers the large one.  A stream-K launch (hybrid schedule,
+// sk_schedule.h) takes T / 256 rounds, not rounded up, plus one hand-off: 7.5 us fitted on the short-K launches, which
+// lose exactly that.  (A two-wave 64x32 tile was tried for the 13x13 maps at batch 16, which are short of blocks: 461 vs
+// 337 us on the K = 9216 data gradients.)
+#pragma once
+
+#include <algorithm>
+
+struct VyTileModel {
+  int bm, bn;
+  double alpha, fixed;
+  int resident;  // blocks per CU
+};
+static const VyTileModel kVyTileModels[3] = {{128, 128, 0.0543, 4.5, 2}, {128, 64, 0.0273, 2.6, 3}, {64, 64, 0.0145, 1.4, 4}};
+
+inline const VyTileModel* vy_tile_model(int bm, int bn) {
+  for (const VyTileModel& t : kVyTileModels)
+    if (t.bm == bm && t.bn == bn) return &t;
+  return nullptr;
+}
+
+struct VySkPolicy {
+  bool allowed;     // stream-K instances may be used for this launch at all
+  double min_gain;  // fraction of the plain launch the predicted saving has to reach (0.03)
+  double cost;      // microseconds of one hand-off (7.5)
+};
+
+// predicted time (microseconds) of a launch of M x N outputs with reduction length K on tile t; *use_sk: as stream-K
+inline double vy_predict_launch(long long M, int N, double K, const VyTileModel& t, const VySkPolicy& p, bool* use_sk) {
+  const long long tiles = ((M + t.bm - 1) / t.bm) * ((N + t.bn - 1) / t.bn);
+  const double t_round = t.alpha * K + t.fixed;
+  // a block that has a CU to itself (one wave per SIMD) runs over the model: nobody covers its LDS-DMA latency.  Small
+  // tiles 10-19 % (their four-stage instance); a 128x128 block 25-33 % (k-loop of 20.6 us for 15.5 in a pair,
+  // tools/probe/conv_tile_trace.hip; the 26x26 training layers: 195 us as 128x128 stream-K with one block per CU against
+  // 182 us as 128x64 stream-K with two)
+  const double lone = t.bm * t.bn < 128 * 128 ? 1.12 : 1.25;
+  double t_plain = (double)((tiles + 255) / 256) * t_round;
+  if (tiles < 256) t_plain *= lone;
+  *use_sk = false;
+  if (p.allowed && tiles > 256) {
+    const long long per_cu = std::min<long long>(t.resident, tiles / 256);  // a share is at least one tile
+    if (tiles > 256 * per_cu) {
+      double t_sk = (double)tiles / 256.0 * t_round;
+      if (per_cu == 1) t_sk *= lone;
+      t_sk += p.cost;
+      if (t_plain - t_sk >= p.min_gain * t_plain) {
+        *use_sk = true;
+        return t_sk;
+      }
+    }
+  }
+  return t_plain;
+}
+
+// the block tile with the smallest predicted time (a smaller tile has to be better by 0.5 %); N <= 32 has its own tile
+inline double vy_select_tile(long long M, int N, double K, const VySkPolicy& p, int* bm, int* bn, bool* use_sk) {
+  if (N <= 32) {
+    *bm = 128, *bn = 32, *use_sk = false;
+    return 0.0;
+  }
+  double best = 1e300;
+  for (const VyTileModel& c : kVyTileModels) {
+    if (c.bn == 128 && N <= 64) continue;
+    bool sk;
+    const double t = vy_predict_launch(M, N, K, c, p, &sk);  // as a plain or a stream-K launch, whichever will be used
+    if (t < best * 0.995) {
+      best = t;
+      *bm = c.bm;
+      *bn = c.bn;
+      *use_sk = sk;
+    }
+  }
+  return best;
+}

@@ -41,6 +41,7 @@
 
 #include "conv_device.h"
 #include "sk_schedule.h"
+#include "conv_cost_model.h"
 
 // Stream-K hand-off between the block that starts a tile and the block that finishes it (SK instances only).
 // `tiles` tiles in the launch (the grid is smaller); partials: [grid][BM * BN] floats; flags: [grid] words, zero between
@@ -632,25 +633,7 @@ static int cu_count() {
   return n;
 }
 
-// ---- the launch cost model, shared by the tile choice (select_cfg) and the stream-K decision (launch_cfg) ----
-// Measured on the MI355X (tools/train_layers.sh with VY_CONV_FORCE, 416x416 batch 16 and 608x608 batch 64): a launch of T
-// tiles takes ceil(T / 256) x (alpha(tile) x K + O(tile)) — every CU works through its share of the tiles at a rate that
-// does not depend on how many blocks it holds (2 resident 128x128 blocks, 3 of 128x64, 4 of 64x64), and what is lost is
-// the last, partly filled round of the 256 CUs.  Fitted per tile, in microseconds: alpha = 0.0543 / 0.0273 / 0.0145 per
-// unit of K, fixed part O = 4.5 / 2.6 / 1.4 (prologue tables + the epilogue of 64 / 32 / 16 accumulator registers per
-// lane).  A stream-K launch (hybrid schedule, see the kernel) takes T / 256 rounds, not rounded up, plus one hand-off:
-// 7.5 us fitted on the short-K launches, which lose exactly that.
-struct TileModel {
-  int bm, bn;
-  double alpha, fixed;
-  int resident;  // blocks per CU
-};
-static const TileModel kTileModels[3] = {{128, 128, 0.0543, 4.5, 2}, {128, 64, 0.0273, 2.6, 3}, {64, 64, 0.0145, 1.4, 4}};
-static const TileModel* tile_model(int bm, int bn) {
-  for (const TileModel& t : kTileModels)
-    if (t.bm == bm && t.bn == bn) return &t;
-  return nullptr;
-}
+// ---- the launch cost model (conv_cost_model.h), shared by the tile choice (select_cfg) and the stream-K decision ----
 struct SkSwitches {
   int on, dgrad, slots;
   double min_gain, cost;
@@ -671,27 +654,8 @@ static bool sk_allowed(const ConvArgs& a) {
   const SkSwitches& w = sk_switches();
   return w.on && a.sk_partials && a.sk_flags && (!a.dgrad || w.dgrad || w.slots > 0);
 }
-// predicted time of the launch on tile t (microseconds); *use_sk: as a stream-K launch
-static double predict_launch(const ConvArgs& a, const TileModel& t, bool* use_sk) {
-  const long long tiles = (long long)((a.M + t.bm - 1) / t.bm) * ((a.N + t.bn - 1) / t.bn);
-  const double t_round = t.alpha * ((double)a.ntaps * a.Kc) + t.fixed;
-  const bool small = t.bm * t.bn < 128 * 128;
-  double t_plain = (double)((tiles + 255) / 256) * t_round;
-  if (tiles < 256 && small) t_plain *= 1.12;  // lone small blocks (one wave per SIMD) run 10-19 % over the model
-  *use_sk = false;
-  if (sk_allowed(a) && tiles > 256) {
-    const long long per_cu = std::min<long long>(t.resident, tiles / 256);  // a share is at least one tile
-    if (tiles > 256 * per_cu) {
-      double t_sk = (double)tiles / 256.0 * t_round;
-      if (per_cu == 1 && small) t_sk *= 1.12;
-      t_sk += sk_switches().cost;
-      if (t_plain - t_sk >= sk_switches().min_gain * t_plain) {
-        *use_sk = true;
-        return t_sk;
-      }
-    }
-  }
-  return t_plain;
+static VySkPolicy sk_policy(const ConvArgs& a) {
+  return VySkPolicy{sk_allowed(a), sk_switches().min_gain, sk_switches().cost};
 }
 
 // `sk_query` != nullptr: nothing is launched, *sk_query tells whether the launch would be a stream-K one (the profile's label)
@@ -715,7 +679,8 @@ static hipError_t launch_cfg(const ConvArgs& a, hipStream_t s, bool* sk_query = 
     const long long per_cu = std::min<long long>(a.dgrad ? res_d : res_f, tiles / cus);
     const long long G = sk_slots > 0 ? sk_slots : (long long)cus * per_cu;
     bool pays = false;
-    if (const TileModel* tm = tile_model(BM, BN)) predict_launch(a, *tm, &pays);
+    if (const VyTileModel* tm = vy_tile_model(BM, BN))
+      vy_predict_launch(a.M, a.N, (double)a.ntaps * a.Kc, *tm, sk_policy(a), &pays);
     if (G > 0 && tiles > G && tiles * (G + 8) < (1ll << 31) && 2 * (G / 8 + 1) * (long long)(a.ntaps * (a.Kc >> 5)) < (1ll << 31) &&
         (sk_slots > 0 || pays) && G * BM * BN * 4ll <= (long long)a.sk_bytes && G <= a.sk_nflags) {
       if (sk_query) {
@@ -747,16 +712,7 @@ static hipError_t launch_cfg(const ConvArgs& a, hipStream_t s, bool* sk_query = 
   return hipGetLastError();
 }
 
-// Tile choice.  Measured on the MI355X (tools/train_layers.sh with VY_CONV_FORCE, 416x416 batch 16 and 608x608
-// batch 64): a launch of T tiles takes ceil(T / 256) x (alpha(tile) x K + O(tile)) — every CU works through its
-// share of the tiles at a rate that does not depend on how many blocks it holds (2 resident 128x128 blocks, 3 of
-// 128x64, 4 of 64x64), and what is lost is the last, partly filled round of the 256 CUs.  Fitted per tile, in
-// microseconds (refitted after the k-loop lost its vector instructions): alpha = 0.0543 / 0.0273 / 0.0145 per unit
-// of K (the 128x64 tile now costs exactly half of 128x128: its old 0.547 was the vector-instruction overhead of twice
-// the DMA instructions per FLOP), fixed part O = 4.5 / 2.6 / 1.4 (prologue tables + the epilogue of 64 / 32 / 16
-// accumulator registers per lane): short-K 1x1 layers prefer the small tiles, long-K 3x3 layers the large one.
-// The smallest predicted time wins; a smaller tile has to be better by 0.5 %.  (A two-wave 64x32 tile was tried
-// for the 13x13 maps at batch 16, which are short of blocks: 461 vs 337 us on the K = 9216 data gradients.)
+// Tile choice: conv_cost_model.h, plus the experiment switches.
 static void select_cfg(const ConvArgs& a, int* bm, int* bn) {
   auto blocks = [&](int m, int n) { return (long long)((a.M + m - 1) / m) * ((a.N + n - 1) / n); };
   // experiment switch (tools/train_layers.sh): VY_CONV_FORCE=128x64 runs every launch on that tile
@@ -767,18 +723,9 @@ static void select_cfg(const ConvArgs& a, int* bm, int* bn) {
     *bn = 32;
     return;
   }
-  double best = 1e300;
-  for (const TileModel& c : kTileModels) {
-    if (c.bn == 128 && a.N <= 64) continue;
-    bool sk;
-    const double t = predict_launch(a, c, &sk);  // as a plain or a stream-K launch, whichever the launcher will pick
-    if (t < best * 0.995) {
-      best = t;
-      *bm = c.bm;
-      *bn = c.bn;
-    }
-  }
   const double K = (double)a.ntaps * a.Kc;
+  bool sk_unused;
+  double best = vy_select_tile(a.M, a.N, K, sk_policy(a), bm, bn, &sk_unused);
   // 16x16 wave tiles (conv_small.hip; block tile 32 x {32, 64}): OFF by default.  Measured on the MI355X (round 3,
   // profiles/r03_negative_results.txt): bit-exact, but 1.9 - 2.0x SLOWER than the 64x64 tile on the batch-1 3x3 layers it
   // was built for (76x76: 78-85 vs 42 us, 38x38: 85-88 vs 43, 19x19: 98-128 vs 77) — a 32-channel sub-step of a 32x32
