@@ -82,8 +82,18 @@ int main(int argc, char** argv) {
   a.w_taps = k * k; a.w_cin = Cin; a.w_cout = Cout; a.N = Cout;
   a.o_Hp = Ho + 2; a.o_Wp = Ho + 2; a.o_cs = Cout; a.o_co = 0; a.o_s = 1; a.o_oy = a.o_ox = 1; a.ups = 1;
   a.r_cs = Cout; a.r_co = 0; a.leaky = 1; a.dgrad = 0;
+  {  // stream-K scratch, as a net's workspace provides it (zeroed: all flags down)
+    void* skp;
+    CK(hipMalloc(&skp, (size_t)VY_SK_PARTIAL_BYTES + (size_t)VY_SK_FLAGS * 4));
+    CK(hipMemset(skp, 0, (size_t)VY_SK_PARTIAL_BYTES + (size_t)VY_SK_FLAGS * 4));
+    a.sk_flags = (unsigned*)skp;
+    a.sk_partials = (float*)((char*)skp + (size_t)VY_SK_FLAGS * 4);
+    a.sk_bytes = VY_SK_PARTIAL_BYTES;
+    a.sk_nflags = VY_SK_FLAGS;
+  }
   int bm, bn;
   vy_conv_cfg(a, &bm, &bn);
+  const bool streamk = vy_conv_streamk(a);
   const long long tiles = (long long)((a.M + bm - 1) / bm) * ((a.N + bn - 1) / bn);
   unsigned long long* trace;
   CK(hipMalloc(&trace, (size_t)tiles * 8 * 8));
@@ -101,8 +111,10 @@ int main(int argc, char** argv) {
   CK(hipEventElapsedTime(&ms, e0, e1));
   const double us = ms * 1000.0 / reps, K = (double)k * k * Cin;
   const double gflop = 2.0 * a.M * (double)Cout * K * 1e-9;
-  printf("conv B=%d H=%d Cin=%d Cout=%d k=%d s=%d res=%d %s | M=%d N=%d K=%.0f tile %dx%d tiles=%lld | %.1f us  %.1f TF\n",
-         B, H, Cin, Cout, k, stride, res, random_data ? "random" : "zeros ", a.M, a.N, K, bm, bn, tiles, us, gflop / us * 1e3);
+  printf("conv B=%d H=%d Cin=%d Cout=%d k=%d s=%d res=%d %s | M=%d N=%d K=%.0f tile %dx%d%s tiles=%lld | %.1f us  %.1f TF\n",
+         B, H, Cin, Cout, k, stride, res, random_data ? "random" : "zeros ", a.M, a.N, K, bm, bn, streamk ? "sk" : "", tiles, us,
+         gflop / us * 1e3);
+  if (streamk) return 0;  // (the per-block trace below assumes one tile per block)
   CK(hipMemset(trace, 0, (size_t)tiles * 8 * 8));
   a.trace = trace;
   CK(vy_launch_conv_igemm(a, 0));
