@@ -580,7 +580,10 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_kernel(const ConvA
 #if defined(__HIP_DEVICE_COMPILE__)  // the host pass only needs the launch stub (amdgcn builtins below)
   constexpr int STAGE = (BM + BN) * 128;
   // one LDS object: [stage0 A|W][stage1 A|W]...[row tables]
-  __shared__ __attribute__((aligned(16))) unsigned char smem[NS * STAGE + 2 * BM * 8];
+#ifndef VY_CONV_PAD_LDS  // probe builds only (tools/probe): extra LDS per block to lower the blocks a CU holds
+#define VY_CONV_PAD_LDS 0
+#endif
+  __shared__ __attribute__((aligned(16))) unsigned char smem[NS * STAGE + 2 * BM * 8 + (NS == 2 ? VY_CONV_PAD_LDS : 0)];
   // XCD-aware order: blocks L, L+8, ... share an XCD (L2); give each XCD a contiguous run of tiles (SK: of the
   // k-step sequence) with n fastest so neighbours in time re-use the same A rows and the whole W panel.
   int vblk;
