@@ -103,7 +103,7 @@ int main(int argc, char** argv) {
   a.trace = nullptr;
   for (int i = 0; i < 3; ++i) CK(vy_launch_conv_igemm(a, 0));
   CK(hipEventRecord(e0, 0));
-  const int reps = 20;
+  const int reps = getenv("VY_TRACE_REPS") ? atoi(getenv("VY_TRACE_REPS")) : 20;  // (clock_under_load.sh: seconds of the same launch)
   for (int i = 0; i < reps; ++i) CK(vy_launch_conv_igemm(a, 0));
   CK(hipEventRecord(e1, 0));
   CK(hipEventSynchronize(e1));
