@@ -115,6 +115,26 @@ int vy_net_bind_workspace(vy_net* net, void* dev_ws, size_t bytes, int32_t batch
  * plans always keep every plane (backward reads them). */
 int vy_net_set_keep_activations(vy_net* net, int32_t keep);
 
+/* Arithmetic of the inference convolutions (Conv2D inside `_conv2d`, models/definitions/layers.py:63-70; SURVEY 7
+ * hard-part (iii) admits "split-fp32").  No counterpart in the reference: mxnet picks its conv algorithm itself.
+ *   VY_CONV_EXACT_FP32     default, the parity path: every output one fp32 fma chain on v_mfma_f32_32x32x2_f32,
+ *                          bit-identical to oracle/ 
+ *   VY_CONV_SPLIT_BF16X3   opt-in: the 3x3 cells with cout % 128 == 0 run on the bf16 matrix core — every fp32
+ *                          operand cut exactly into three bf16 numbers, six partial products per multiply, fp32
+ *                          accumulation (csrc/conv_split.hip); NOT bit-equal to the exact path (tolerances:
+ *                          tests/test_gpu_split.py), 1.4-1.5x faster on those layers.  Planes, stem, 1x1 convs,
+ *                          decode and NMS are shared with the exact path.  Training always runs the exact kernels.
+ * Changes the plan (the pre-split weight images live in the workspace): call before vy_net_workspace_bytes /
+ * vy_net_bind_workspace; a bound workspace is unbound by a change. */
+enum vy_conv_mode { VY_CONV_EXACT_FP32 = 0, VY_CONV_SPLIT_BF16X3 = 1 };
+int vy_net_set_conv_mode(vy_net* net, int32_t mode);
+int32_t vy_net_get_conv_mode(const vy_net* net);
+/* The weight images of VY_CONV_SPLIT_BF16X3 are rebuilt by the next inference forward after any parameter write the
+ * library performs itself (vy_net_bind_params, vy_net_param_set, vy_net_sgd_step, vy_net_bind_workspace).  A caller
+ * that writes the device parameter buffer directly (the Trainer's broadcast from rank 0, train_yolov3.py:527-530)
+ * says so with this call. */
+int vy_net_invalidate_split_weights(vy_net* net);
+
 /* Number of anchors N = 3 * sum_i (H/s_i)(W/s_i) for the planned shape. */
 int32_t vy_net_num_anchors(const vy_net* net);
 

@@ -11,10 +11,12 @@ ap.add_argument("--size", type=int, default=608)
 ap.add_argument("--batch", type=int, default=64)
 ap.add_argument("--classes", type=int, default=20)
 ap.add_argument("--out", default=None)
+ap.add_argument("--conv-mode", default="exact", choices=["exact", "split_bf16x3"])
 a = ap.parse_args()
 net = vy.yolo3_darknet53(["c%d" % i for i in range(a.classes)], pretrained_base=False)
 net.initialize(init="synthetic", seed=233)
 net.collect_params().reset_ctx("cuda:0")
+net.set_conv_mode(a.conv_mode)
 x = torch.randn((a.batch, 3, a.size, a.size), device="cuda:0")
 for _ in range(2):
     net(x)

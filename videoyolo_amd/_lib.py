@@ -7,6 +7,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libvyolo.so")
 
 VY_MAX_TOPK = 1024
+VY_CONV_EXACT_FP32, VY_CONV_SPLIT_BF16X3 = 0, 1
 
 
 class VyError(RuntimeError):
@@ -46,6 +47,9 @@ SIGNATURES = {
     "vy_net_workspace_bytes": (_sz, [_vp, _i32, _i32, _i32]),
     "vy_net_bind_workspace": (ctypes.c_int, [_vp, _vp, _sz, _i32, _i32, _i32, _vp]),
     "vy_net_set_keep_activations": (ctypes.c_int, [_vp, _i32]),
+    "vy_net_set_conv_mode": (ctypes.c_int, [_vp, _i32]),
+    "vy_net_get_conv_mode": (_i32, [_vp]),
+    "vy_net_invalidate_split_weights": (ctypes.c_int, [_vp]),
     "vy_net_num_anchors": (_i32, [_vp]),
     "vy_net_forward_infer": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "vy_net_read_head": (ctypes.c_int, [_vp, _i32, _vp, _vp]),

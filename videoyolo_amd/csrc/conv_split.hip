@@ -1,0 +1,408 @@
+// conv_split.hip — OPT-IN "split-fp32" forward convolution on the gfx950 bf16 matrix core (bf16 x 3, six partial
+// products, fp32 accumulate).  Not the parity path: conv_igemm.hip (exact fp32 fma chains) stays the default and
+// the headline; this instance is selected per net with vy_net_set_conv_mode(net, VY_CONV_SPLIT_BF16X3) and is
+// reported separately by bench.py.
+//
+// Replaces the same reference operator chain as conv_igemm.hip (models/definitions/layers.py:63-70: Conv2D ->
+// BatchNorm -> LeakyReLU(0.1); residual add darknet/three_darknet.py:119-123; `_upsample` + concat
+// layers.py:11-20, yolo3.py:1167-1177) for the layers whose contraction is long enough to be matrix-bound.
+// SURVEY 7 hard-part (iii) names split-fp32 as admissible where 1e-4 agreement is kept.
+//
+// Arithmetic.  Every fp32 operand x is cut into three bf16 numbers, round-to-nearest-even each time:
+//     h = bf16(x),  m = bf16(x - h),  l = bf16(x - h - m)          (x - h and x - h - m are exact in fp32)
+// so x = h + m + l EXACTLY (8 + 8 + 8 significand bits, |m| <= 2^-9 |x|, |l| <= 2^-17 |x|).  A product x*w is
+// evaluated as  l_x h_w + h_x l_w + m_x m_w + m_x h_w + h_x m_w + h_x h_w  — six v_mfma_f32_32x32x16_bf16 per
+// 16 channels, each bf16 x bf16 product exact, accumulated in fp32; the three products left out (m l, l m, l l)
+// are below 2^-25 |x w|, i.e. below the rounding of the fp32 accumulation itself.  The result is NOT bit-equal to
+// the exact chain (different summation tree inside the matrix core); tests/test_gpu_split.py holds the tolerances.
+//
+// Data flow.  Activation planes stay fp32 (kernels.h) — the split happens in registers on the way into LDS, so
+// every other kernel of the net (stem, 1x1 convs on the exact kernel, decode) is shared with the exact path:
+//   A (pixels): global_load_dwordx4 x2 per thread and k-step (8 channels of one pixel) -> 3 x 4 packed dwords
+//               (11 vector instructions per channel pair, beside the bf16 MFMAs, which do not use the vector
+//               pipe's FMA hardware the way the fp32 MFMA does) -> ds_write_b128 x3
+//   W:          pre-split ONCE per parameter change by split_weights_kernel into the exact LDS tile images
+//               [cout / 32][k-step][plane][32 rows][16 channels], so a k-step of a 128-channel tile is twelve
+//               1-KiB LDS-DMA instructions (global_load_lds_dwordx4) reading consecutive memory
+//   LDS stage:  [plane][row][2 x 16 B], the 16-B slot XOR-ed with bit 3 of the row: conflict-free ds_read_b128
+// Block = 4 waves (2 x 2), tile 128 pixels x 128 channels, k-step 16 channels, three LDS stages (72 KiB: two
+// blocks per CU, so one block's epilogue runs in the shadow of the other's k-loop).
+#include <cstdio>
+#include <cstdlib>
+#include <type_traits>
+
+#include "kernels.h"
+#include "../../include/vy_math.h"
+#include "conv_device.h"
+
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// two fp32 -> one dword of two bf16 (RNE), element 0 in the low half
+__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
+  unsigned r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+  return r;
+}
+
+// 8 consecutive channels -> the three bf16 planes (4 dwords each)
+__device__ __forceinline__ void split8(const f32x4 v0, const f32x4 v1, vy_u32x4& H, vy_u32x4& M, vy_u32x4& L) {
+  const float x[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float x0 = x[2 * j], x1 = x[2 * j + 1];
+    const unsigned h = cvt_pk_bf16(x0, x1);
+    const float r0 = x0 - __builtin_bit_cast(float, h << 16), r1 = x1 - __builtin_bit_cast(float, h & 0xffff0000u);
+    const unsigned m = cvt_pk_bf16(r0, r1);
+    const float l0 = r0 - __builtin_bit_cast(float, m << 16), l1 = r1 - __builtin_bit_cast(float, m & 0xffff0000u);
+    H[j] = h;
+    M[j] = m;
+    L[j] = cvt_pk_bf16(l0, l1);
+  }
+}
+#endif
+
+// fp32 weights [cout][taps][cin] -> bf16 tile images: image (ng, ks, p) is 1 KiB = [32 rows][2 slots][8 channels],
+// row r = cout % 32, k-step ks = tap * (cin / 16) + cin / 16 index, slot s holds channel octet s ^ ((r >> 3) & 1)
+__global__ void split_weights_kernel(const float* __restrict__ w, unsigned short* __restrict__ img, const int cout,
+                                     const int taps, const int cin) {
+  const long long total = (long long)cout * taps * cin;
+  const int KS = taps * (cin >> 4);
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(e % cin);
+    const long long t_ = e / cin;
+    const int tap = (int)(t_ % taps), n = (int)(t_ / taps);
+    const float x = w[e];
+    auto rne = [](float f) -> unsigned {
+      const unsigned u = __builtin_bit_cast(unsigned, f);
+      return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+    };
+    const unsigned h = rne(x);
+    const float r = x - __builtin_bit_cast(float, h << 16);
+    const unsigned m = rne(r);
+    const float q = r - __builtin_bit_cast(float, m << 16);
+    const unsigned l = rne(q);
+    const int ng = n >> 5, row = n & 31, ks = tap * (cin >> 4) + (c >> 4), oct = (c >> 3) & 1, j = c & 7;
+    const long long base = (((long long)ng * KS + ks) * 3) * 512 + row * 16 + ((oct ^ ((row >> 3) & 1)) << 3) + j;
+    img[base] = (unsigned short)h;
+    img[base + 512] = (unsigned short)m;
+    img[base + 1024] = (unsigned short)l;
+  }
+}
+
+size_t vy_split_weight_bytes(int cout, int taps, int cin) { return (size_t)((cout + 31) / 32) * taps * (cin / 16) * 3072; }
+
+hipError_t vy_launch_split_weights(const float* w, void* img, int cout, int taps, int cin, hipStream_t s) {
+  if (cout % 32 != 0 || cin % 16 != 0) return hipErrorInvalidValue;
+  const long long total = (long long)cout * taps * cin;
+  const int blocks = (int)std::min<long long>((total + 255) / 256, 8192);
+  hipLaunchKernelGGL(split_weights_kernel, dim3(blocks), dim3(256), 0, s, w, (unsigned short*)img, cout, taps, cin);
+  return hipGetLastError();
+}
+
+template <int BM, int BN>
+__global__ __launch_bounds__(256, 2) void conv_split_kernel(const ConvArgs a, const int tiles_n) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int WM = 2, WN = 2, NW = 4, NT = 256;
+  constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+  constexpr int NS = 3;
+  constexpr int A_PL = BM * 32, W_PL = BN * 32;          // bytes of one plane of a stage (rows x 32 B)
+  constexpr int A_ST = 3 * A_PL, W_ST = 3 * W_PL, STAGE = A_ST + W_ST;
+  constexpr int W_INSTR = (BN / 32) * 3 / NW;            // LDS-DMA instructions per wave per k-step
+  constexpr int A_SETS = BM * 2 / NT;                    // (row, octet) pairs per thread per k-step
+  static_assert((BN / 32) * 3 % NW == 0 && A_SETS >= 1 && TM >= 1 && TN >= 1, "tile");
+  __shared__ __attribute__((aligned(16))) unsigned char smem[NS * STAGE + BM * 16];
+  long long* in_off = reinterpret_cast<long long*>(smem + NS * STAGE);
+  unsigned* o_off = reinterpret_cast<unsigned*>(in_off + BM);
+  unsigned* r_off = o_off + BM;
+  constexpr unsigned kInvalidRow = 0x80000000u;
+
+  // XCD-aware order (conv_igemm.hip): blocks L, L+8, ... share an L2; contiguous run of tiles per XCD, n fastest
+  int vblk;
+  {
+    const int nblk = gridDim.x, L = blockIdx.x;
+    const int q = nblk >> 3, r = nblk & 7, xcd = L & 7, idx = L >> 3;
+    vblk = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int h = lane >> 5, lrow = lane & 31;
+  const int cch = a.Kc >> 4;  // 16-channel chunks per tap
+  const int tile_m = vblk / tiles_n, tile_n = vblk - tile_m * tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  long long pix0;
+  {
+    const int t = (int)fd_div((unsigned)m0, a.fd_lw);
+    const int x = m0 - t * a.LW;
+    const int b = (int)fd_div((unsigned)t, a.fd_lh);
+    const int y = t - b * a.LH;
+    const long long p = (long long)(b * a.o_Hp + y * a.o_s + a.o_oy) * a.o_Wp + x * a.o_s + a.o_ox;
+    pix0 = ((long long)__builtin_amdgcn_readfirstlane((int)(p >> 32)) << 32) |
+           (unsigned)__builtin_amdgcn_readfirstlane((int)p);
+  }
+  for (int rr = tid; rr < BM; rr += NT) {
+    const int m = m0 + rr;
+    const int mm = m < a.M ? m : a.M - 1;
+    const int t = (int)fd_div((unsigned)mm, a.fd_lw);
+    const int x = mm - t * a.LW;
+    const int b = (int)fd_div((unsigned)t, a.fd_lh);
+    const int y = t - b * a.LH;
+    in_off[rr] = ((long long)(b * a.a_Hp + y * a.a_s + a.a_oy) * a.a_Wp + x * a.a_s + a.a_ox) * a.a_cs + a.a_co;
+    const unsigned rel = (unsigned)(((long long)(b * a.o_Hp + y * a.o_s + a.o_oy) * a.o_Wp + x * a.o_s + a.o_ox) - pix0);
+    unsigned oo_row = (m < a.M) ? rel * (unsigned)a.o_cs * 4u : kInvalidRow;
+    if (a.ups == 2 && m < a.M) oo_row |= (2 * x + 1 >= a.o_Wp - 2 ? 1u : 0u) | (2 * y + 1 >= a.o_Hp - 2 ? 2u : 0u);
+    o_off[rr] = oo_row;
+    r_off[rr] = (m < a.M) ? rel * (unsigned)a.r_cs * 4u : kInvalidRow;
+  }
+  __syncthreads();
+
+  // A side: thread -> (row, channel octet) of the tile; pointer to the row's centre pixel
+  const float* a_ptr[A_SETS];
+  unsigned a_lds[A_SETS];  // byte offset inside a stage's plane 0
+#pragma unroll
+  for (int q = 0; q < A_SETS; ++q) {
+    const int idx = q * NT + tid, row = idx >> 1, oct = idx & 1;
+    a_ptr[q] = a.in + in_off[row] + oct * 8;
+    a_lds[q] = (unsigned)(row * 32 + ((oct ^ ((row >> 3) & 1)) << 4));
+  }
+  // W side: DMA instruction q = j * NW + wave covers row group g = q / 3 of plane p = q % 3
+  const int KS = a.w_taps * cch;
+  unsigned w_voff[W_INSTR], w_lds[W_INSTR];
+#pragma unroll
+  for (int j = 0; j < W_INSTR; ++j) {
+    const int q = j * NW + wave, g = q / 3, p = q - g * 3;
+    w_voff[j] = (unsigned)(g * KS * 3072 + p * 1024 + lane * 16);
+    w_lds[j] = (unsigned)(A_ST + p * W_PL + g * 1024);
+  }
+  const unsigned char* w_tile = reinterpret_cast<const unsigned char*>(a.w_split) + (long long)(n0 >> 5) * KS * 3072;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+  const unsigned lds0 = (unsigned)(unsigned long long)LDS_PTR(smem);
+  const int T = a.ntaps * cch;
+
+  // wave-uniform k-step state
+  int n_tap = 0, n_cc = 0;
+  int a_koff = 0;
+  long long w_koff = 0;
+  auto advance = [&]() {
+    const int tdy = (int)((a.pk_dy >> (2 * n_tap)) & 3u) - 1, tdx = (int)((a.pk_dx >> (2 * n_tap)) & 3u) - 1;
+    const int tw = (int)((a.pk_w >> (4 * n_tap)) & 15ull);
+    a_koff = (tdy * a.a_Wp + tdx) * a.a_cs + n_cc * 16;
+    w_koff = (long long)(tw * cch + n_cc) * 3072;
+    if (++n_cc == cch) {
+      n_cc = 0;
+      ++n_tap;
+    }
+  };
+  f32x4 av[A_SETS][2];
+  auto load_a = [&]() {
+#pragma unroll
+    for (int q = 0; q < A_SETS; ++q) {
+      const f32x4* p = reinterpret_cast<const f32x4*>(a_ptr[q] + a_koff);
+      av[q][0] = p[0];
+      av[q][1] = p[1];
+    }
+  };
+  auto dma_w = [&](int stage) {
+#pragma unroll
+    for (int j = 0; j < W_INSTR; ++j)
+      lds_dma16_s(w_voff[j], reinterpret_cast<const float*>(w_tile + w_koff), lds0 + stage * STAGE + w_lds[j]);
+  };
+  auto store_a = [&](int stage) {
+#pragma unroll
+    for (int q = 0; q < A_SETS; ++q) {
+      vy_u32x4 H, M, L;
+      split8(av[q][0], av[q][1], H, M, L);
+      unsigned char* d = smem + stage * STAGE + a_lds[q];
+      *reinterpret_cast<vy_u32x4*>(d) = H;
+      *reinterpret_cast<vy_u32x4*>(d + A_PL) = M;
+      *reinterpret_cast<vy_u32x4*>(d + 2 * A_PL) = L;
+    }
+  };
+  // fragment read offsets (inside a stage): row * 32 + swizzled octet
+  const unsigned fa = (unsigned)((wm * (BM / WM) + lrow) * 32 + ((h ^ ((lrow >> 3) & 1)) << 4));
+  const unsigned fw = (unsigned)(A_ST + (wn * (BN / WN) + lrow) * 32 + ((h ^ ((lrow >> 3) & 1)) << 4));
+
+  auto kstep = [&](auto stage_, auto has1_, auto has2_) {
+    constexpr int ST = decltype(stage_)::value;
+    constexpr bool HAS1 = decltype(has1_)::value, HAS2 = decltype(has2_)::value;
+    lds_barrier();  // stage ST complete (A by ds_write, W by DMA waited for one k-step ago) and visible
+    if (HAS1) {     // k-step t+1: its A values arrived while the previous k-step computed
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      store_a((ST + 1) % NS);
+    }
+    if (HAS2) {     // k-step t+2: issue its loads now, a whole k-step of matrix work ahead of their use
+      advance();
+      load_a();
+      dma_w((ST + 2) % NS);
+    }
+    const unsigned char* sb = smem + ST * STAGE;
+    bf16x8 af[3][TM], wf[3][TN];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[p][i] = *reinterpret_cast<const bf16x8*>(sb + fa + p * A_PL + i * 1024);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) wf[p][j] = *reinterpret_cast<const bf16x8*>(sb + fw + p * W_PL + j * 1024);
+    }
+    // smallest terms first: (l,h) (h,l) (m,m) (m,h) (h,m) (h,h); plane 0 = h, 1 = m, 2 = l
+    constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PW[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+    for (int t = 0; t < 6; ++t)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[PA[t]][i], wf[PW[t]][j], acc[i][j], 0, 0, 0);
+  };
+
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, 1>;
+  using S2 = std::integral_constant<int, 2>;
+  using Y = std::true_type;
+  using N_ = std::false_type;
+  // prologue: k-step 0 into stage 0 (A through registers, W by DMA), k-step 1's loads in flight
+  advance();
+  load_a();
+  dma_w(0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  store_a(0);
+  if (T > 1) {
+    advance();
+    load_a();
+    dma_w(1);
+  }
+  int t = 0;
+  for (; t + 5 <= T; t += 3) {  // t+2, t+3, t+4 all have a k-step two ahead
+    kstep(S0{}, Y{}, Y{});
+    kstep(S1{}, Y{}, Y{});
+    kstep(S2{}, Y{}, Y{});
+  }
+  auto tail = [&](auto stage_, int tt) {
+    const int after = T - 1 - tt;
+    if (after >= 2) kstep(stage_, Y{}, Y{});
+    else if (after == 1) kstep(stage_, Y{}, N_{});
+    else kstep(stage_, N_{}, N_{});
+  };
+  for (; t < T; t += 3) {
+    tail(S0{}, t);
+    if (t + 1 < T) tail(S1{}, t + 1);
+    if (t + 2 < T) tail(S2{}, t + 2);
+  }
+
+  // ---- epilogue (conv_igemm.hip): affine -> leaky -> + addend -> store (x1 or x2-replicated)
+  constexpr int kRsrcFlags = 0x00020000;
+  const __amdgpu_buffer_rsrc_t out_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(a.out + (pix0 * a.o_cs + a.o_co + n0), 0, 0x7fffffff, kRsrcFlags);
+  const __amdgpu_buffer_rsrc_t res_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.res ? a.res + (pix0 * a.r_cs + a.r_co + n0) : a.in), 0, 0x7fffffff, kRsrcFlags);
+  const int ups_dx = a.o_cs * 4, ups_dy = a.o_Wp * a.o_cs * 4;
+  auto epilogue = [&](auto has_scale_, auto leaky_, auto has_res_, auto ups2_) {
+    constexpr bool has_scale = decltype(has_scale_)::value;
+    constexpr bool leaky = decltype(leaky_)::value, has_res = decltype(has_res_)::value, ups2 = decltype(ups2_)::value;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int ncol = (wn * TN + j) * 32 + lrow;
+      const int n = n0 + ncol;
+      const bool nvalid = n < a.N;
+      const int nc = nvalid ? n : a.N - 1;
+      const unsigned colc = (unsigned)ncol * 4u | (nvalid ? 0u : kInvalidRow);
+      float sc = 1.0f, sh = 0.0f;
+      if (has_scale) sc = a.scale[nc];
+      sh = a.shift[nc];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        unsigned oo[16];
+        float rv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          oo[r] = __builtin_elementwise_add_sat(o_off[row], colc);
+          if (has_res) rv[r] = buf_load_f32(res_rsrc, __builtin_elementwise_add_sat(r_off[row], colc));
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float vv = acc[i][j][r];
+          if (has_scale)
+            vv = fmaf(vv, sc, sh);
+          else
+            vv = vv + sh;
+          if (leaky) vv = vy_leaky(vv);
+          if (has_res) vv = vv + rv[r];
+          if (!ups2) {
+            buf_store_f32(vv, out_rsrc, oo[r], 0);
+          } else {
+            const unsigned base = oo[r] & ~3u;
+            const unsigned no_dx = (oo[r] & 1u) << 31, no_dy = (oo[r] & 2u) << 30;
+            buf_store_f32(vv, out_rsrc, base, 0);
+            buf_store_f32(vv, out_rsrc, base | no_dx, ups_dx);
+            buf_store_f32(vv, out_rsrc, base | no_dy, ups_dy);
+            buf_store_f32(vv, out_rsrc, base | no_dx | no_dy, ups_dy + ups_dx);
+          }
+        }
+      }
+    }
+  };
+  {
+    using T_ = std::true_type;
+    using F_ = std::false_type;
+    const bool f_scale = a.scale != nullptr, f_leaky = a.leaky != 0, f_res = a.res != nullptr, f_ups2 = a.ups == 2;
+    if (f_scale && f_leaky && !f_ups2) {
+      if (f_res) epilogue(T_{}, T_{}, T_{}, F_{});
+      else epilogue(T_{}, T_{}, F_{}, F_{});
+    } else if (f_scale && f_leaky && !f_res) {
+      epilogue(T_{}, T_{}, F_{}, T_{});
+    } else if (!f_scale && !f_leaky && !f_ups2 && !f_res) {
+      epilogue(F_{}, F_{}, F_{}, F_{});  // bias only (prediction convs)
+    } else {
+      __builtin_trap();
+    }
+  }
+#endif
+}
+
+bool vy_conv_split_supported(const ConvArgs& a) {
+  if (a.dgrad || a.stats || !a.w_split || !a.shift) return false;
+  if (a.Kc % 32 != 0 || a.N % 128 != 0 || a.ntaps < 1 || a.ntaps > 9) return false;
+  const bool bn_cell = a.scale && a.leaky, bias = !a.scale && !a.leaky && !a.res && a.ups != 2;
+  return (bn_cell && (a.ups != 2 || !a.res)) || bias;
+}
+
+static VyFastDiv split_fastdiv(unsigned d) {
+  unsigned l = 0;
+  while ((1ull << l) < d) ++l;
+  VyFastDiv f;
+  f.m = (unsigned)((((1ull << l) - d) << 32) / d + 1);
+  f.s1 = l < 1 ? l : 1;
+  f.s2 = l > 0 ? l - 1 : 0;
+  return f;
+}
+
+hipError_t vy_launch_conv_split(const ConvArgs& a_in, hipStream_t s) {
+  ConvArgs a = a_in;
+  if (!vy_conv_split_supported(a) || a.LW < 1 || a.LH < 1 || a.M <= 0) return hipErrorInvalidValue;
+  a.fd_lw = split_fastdiv((unsigned)a.LW);
+  a.fd_lh = split_fastdiv((unsigned)a.LH);
+  a.pk_dy = a.pk_dx = 0;
+  a.pk_w = 0;
+  for (int t = 0; t < a.ntaps; ++t) {
+    if (a.tap_dy[t] < -1 || a.tap_dy[t] > 1 || a.tap_dx[t] < -1 || a.tap_dx[t] > 1 || a.tap_w[t] > 15) return hipErrorInvalidValue;
+    a.pk_dy |= (unsigned)(a.tap_dy[t] + 1) << (2 * t);
+    a.pk_dx |= (unsigned)(a.tap_dx[t] + 1) << (2 * t);
+    a.pk_w |= (unsigned long long)a.tap_w[t] << (4 * t);
+  }
+  constexpr int BM = 128, BN = 128;
+  const int tiles_m = (a.M + BM - 1) / BM, tiles_n = a.N / BN;
+  hipLaunchKernelGGL((conv_split_kernel<BM, BN>), dim3(tiles_m * tiles_n), dim3(256), 0, s, a, tiles_n);
+  return hipGetLastError();
+}

@@ -50,6 +50,8 @@ struct ConvArgs {
   unsigned* sk_flags;
   unsigned long long sk_bytes;  // bytes of sk_partials
   int sk_nflags;
+  // conv_split.hip only: this conv's weights as pre-split bf16 tile images (vy_launch_split_weights); nullable
+  const void* w_split;
 };
 #define VY_SK_PARTIAL_BYTES (32u << 20)  // 512 blocks x 128x128 fp32 (the largest instance: 2 blocks per CU x 256 CUs)
 #define VY_SK_FLAGS 2048
@@ -62,6 +64,13 @@ hipError_t vy_launch_conv_s16(const ConvArgs& a, int bm, int bn, hipStream_t s);
 int vy_conv_tiles_m(const ConvArgs& a);
 void vy_conv_cfg(const ConvArgs& a, int* bm, int* bn);  // block tile the launch will use
 bool vy_conv_streamk(const ConvArgs& a);                  // ... and whether it will be a stream-K launch (label "<BM>x<BN>sk")
+
+// Opt-in split-fp32 forward conv on the bf16 matrix core (conv_split.hip: bf16 x 3, six products, fp32 accumulate).
+// Same ConvArgs / planes as vy_launch_conv_igemm, plus a.w_split = the conv's weights as bf16 tile images.
+size_t vy_split_weight_bytes(int cout, int taps, int cin);
+hipError_t vy_launch_split_weights(const float* w, void* img, int cout, int taps, int cin, hipStream_t s);
+bool vy_conv_split_supported(const ConvArgs& a);   // forward, N % 128 == 0, Kc % 32 == 0, an epilogue the kernel has
+hipError_t vy_launch_conv_split(const ConvArgs& a, hipStream_t s);
 
 // stem: 3x3 stride-1 conv from the caller's NCHW image (Cin = 3) into a plane, fused affine+leaky.
 struct StemArgs {

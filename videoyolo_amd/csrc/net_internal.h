@@ -46,6 +46,7 @@ struct ConvT {
   int p_bias;                     // -1 for cells
   int64_t scale_off, shift_off;   // folded BN scratch (element offsets), -1 if none
   int is_stem;
+  int64_t split_off = -1;         // conv mode VY_CONV_SPLIT_BF16X3: byte offset of the bf16 weight images in the workspace region, -1: exact kernel
 };
 
 static const int kAnchors[3][6] = {{10, 13, 16, 30, 33, 23}, {30, 61, 62, 45, 59, 119}, {116, 90, 156, 198, 373, 326}};
@@ -74,6 +75,12 @@ struct vy_net {
   bool fold_uploaded = false;
   bool keep_activations = false;  // vy_net_set_keep_activations: inference planes are not recycled (parity taps)
   bool planes_shared = false;     // the committed plan recycles planes (read_activation is then meaningless)
+  // vy_net_set_conv_mode: VY_CONV_SPLIT_BF16X3 sends the inference launches conv_split.hip can serve through the bf16
+  // matrix core (bf16 x 3, six products, fp32 accumulate); their pre-split weight images live in the workspace and are
+  // rebuilt by the next forward whenever the parameters may have changed (split_dirty)
+  int conv_mode = 0;
+  bool split_dirty = true;
+  size_t wsplit_off = 0;
   struct VyTrain* train = nullptr;  // training planner state, owned by train.hip
 
   int add_param(const std::string& name, int kind, int ndim, const int* shape, int trainable, int backbone) {
@@ -244,6 +251,16 @@ struct vy_net {
   // ---- planning
   static size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
 
+  // which inference launches the split-fp32 kernel takes in conv mode VY_CONV_SPLIT_BF16X3: the 3x3 cells whose tile
+  // geometry it has (cout a multiple of 128).  The 1x1 layers stay on the exact kernel by default (K <= 1024: they
+  // are bound by their epilogue and by HBM, not by the matrix pipe; VY_SPLIT_1X1=1 sends them along for experiments).
+  bool split_eligible(const ConvT& c) const {
+    static const int with_1x1 = getenv("VY_SPLIT_1X1") ? atoi(getenv("VY_SPLIT_1X1")) : 0;
+    if (conv_mode != VY_CONV_SPLIT_BF16X3 || c.is_stem || c.p_gamma < 0) return false;
+    if (c.cout % 128 != 0 || c.cin % 32 != 0) return false;
+    return c.k == 3 || with_1x1;
+  }
+
   // Plane -> storage slot.  keep_all (training, or vy_net_set_keep_activations): every plane has its own storage — the
   // backward pass (and the parity taps) read them all.  Otherwise planes are recycled by liveness: a plane may take over
   // the storage of an earlier plane of the SAME geometry (channel stride and resolution: the zero borders coincide and
@@ -300,6 +317,12 @@ struct vy_net {
     off += al(vy_det_scratch_bytes(b, n_items, num_class));
     const size_t sk_o = off;  // stream-K scratch of the conv launches (conv_igemm.hip): flags first, then the slabs
     off += al((size_t)VY_SK_FLAGS * sizeof(unsigned)) + al(VY_SK_PARTIAL_BYTES);
+    const size_t wsp_off = off;  // split-fp32 weight images (conv mode VY_CONV_SPLIT_BF16X3 only)
+    for (ConvT& c : convs) {
+      const bool el = split_eligible(c);
+      if (commit) c.split_off = el ? (int64_t)(off - wsp_off) : -1;
+      if (el) off += al(vy_split_weight_bytes(c.cout, c.k * c.k, c.cin));
+    }
     const size_t pl_off = off;
     size_t fl = 0;
     const std::vector<int> slot = plane_slots(keep_all);
@@ -324,6 +347,8 @@ struct vy_net {
       fold_desc_off = fold_off;
       det_scratch_off = det_off;
       sk_off = sk_o;
+      wsplit_off = wsp_off;
+      split_dirty = true;
       planes_off = pl_off;
       B = b;
       H = h;
@@ -394,6 +419,7 @@ struct vy_net {
     }
     a.leaky = c.leaky;
     a.dgrad = 0;
+    a.w_split = c.split_off >= 0 ? dev_ws + wsplit_off + c.split_off : nullptr;
     set_sk(a);
     return a;
   }
@@ -456,6 +482,15 @@ struct vy_net {
     hook("bn_fold", 0.0, 0.0, true);
     HIP_TRY(vy_launch_bn_fold(dev_params, fd, (int)folds.size(), 1024, 1e-5f, s));
     hook("bn_fold", 0.0, 0.0, false);
+    if (conv_mode == VY_CONV_SPLIT_BF16X3 && split_dirty) {  // once per parameter change, not per forward
+      hook("split_weights", 0.0, 0.0, true);
+      for (const ConvT& c : convs)
+        if (c.split_off >= 0)
+          HIP_TRY(vy_launch_split_weights(dev_params + params[c.p_weight].info.offset, dev_ws + wsplit_off + c.split_off,
+                                          c.cout, c.k * c.k, c.cin, s));
+      hook("split_weights", 0.0, 0.0, false);
+      split_dirty = false;
+    }
     for (const ConvT& c : convs) {
       if (c.is_stem) {
         StemArgs a;
@@ -480,9 +515,16 @@ struct vy_net {
         const double fl = 2.0 * a.M * (double)a.N * a.ntaps * a.Kc;
         const double by = 4.0 * ((double)B * (a.a_Hp - 2) * (a.a_Wp - 2) * a.Kc + (double)a.M * a.N * a.ups * a.ups +
                                  (double)a.N * a.ntaps * a.Kc + (a.res ? (double)a.M * a.N : 0.0));
+        char nm[96];
+        if (a.w_split && vy_conv_split_supported(a)) {
+          snprintf(nm, sizeof nm, "%s|split128x128", c.name.c_str());
+          hook(nm, fl, by, true);
+          HIP_TRY(vy_launch_conv_split(a, s));
+          hook(nm, fl, by, false);
+          continue;
+        }
         int bm, bn;
         vy_conv_cfg(a, &bm, &bn);
-        char nm[96];
         snprintf(nm, sizeof nm, "%s|%dx%d%s", c.name.c_str(), bm, bn, vy_conv_streamk(a) ? "sk" : "");
         hook(nm, fl, by, true);
         HIP_TRY(vy_launch_conv_igemm(a, s));

@@ -914,6 +914,7 @@ int vy_net_sgd_step(vy_net* net, float lr, float momentum, float wd, float resca
   }
   HIP_TRY(vy_launch_sgd(net->dev_params, t->grads, t->mom, segs, chunks, (int)(t->chunk_seg.size() / 2), lr, momentum,
                         wd, rescale_grad, s));
+  net->split_dirty = true;  // conv mode VY_CONV_SPLIT_BF16X3: the weight images are stale now
   return 0;
 }
 

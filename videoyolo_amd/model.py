@@ -241,6 +241,18 @@ class YOLOV3(object):
         with torch.cuda.device(self._device):
             _lib.check(self._lib.vy_net_param_set(self._h, p.index, value.ctypes.data_as(ctypes.c_void_p),
                                                   self._stream()))
+        self._params_written()
+
+    def _params_written(self):
+        """The device parameter buffer changed: the pre-split weight images of conv mode 'split_bf16x3' (of this
+        handle and of the two-stream twin, which shares the buffer) are rebuilt by the next inference forward."""
+        if getattr(self, "_conv_mode", "exact") == "exact":
+            return
+        _lib.check(self._lib.vy_net_invalidate_split_weights(self._h))
+        tw = getattr(self, "_twin", None)
+        if tw is not None:
+            _lib.check(self._lib.vy_net_invalidate_split_weights(tw["h"]))
+        self._graphs = {}  # a captured forward replays the old images
 
     def reset_ctx(self, ctx):
         """Move the parameters to a device (``net.collect_params().reset_ctx(ctx)``).  ctx: a
@@ -418,6 +430,24 @@ class YOLOV3(object):
         self._plan = None      # the plan changed: size and bind the workspace again at the next call
         self._graphs = {}
 
+    def set_conv_mode(self, mode="exact"):
+        """Arithmetic of the inference convolutions (no counterpart in the reference: mxnet picks its conv
+        algorithm itself).  ``'exact'`` (default): fp32 fma chains, bit-identical to the CPU checker — the parity
+        path.  ``'split_bf16x3'``: opt-in, the 3x3 cells run on the bf16 matrix core with every fp32 operand cut
+        exactly into three bf16 numbers (six partial products, fp32 accumulation; include/vyolo.h
+        ``vy_net_set_conv_mode``); training always uses the exact kernels."""
+        modes = {"exact": _lib.VY_CONV_EXACT_FP32, "split_bf16x3": _lib.VY_CONV_SPLIT_BF16X3}
+        if mode not in modes:
+            raise ValueError("conv mode %r: expected one of %s" % (mode, sorted(modes)))
+        _lib.check(self._lib.vy_net_set_conv_mode(self._h, modes[mode]))
+        self._conv_mode = mode
+        self._plan = None      # the plan changed: size and bind the workspace again at the next call
+        self._graphs = {}
+        tw = getattr(self, "_twin", None)
+        if tw is not None:
+            _lib.check(self._lib.vy_net_set_conv_mode(tw["h"], modes[mode]))
+            tw["plan"] = None
+
     def set_nms(self, nms_thresh=0.45, nms_topk=400, post_nms=100):
         """yolo3.py:1208-1228"""
         self.nms_thresh, self.nms_topk, self.post_nms = nms_thresh, nms_topk, post_nms
@@ -481,6 +511,8 @@ class YOLOV3(object):
         self._sync_hook, self._sync_bn_checked = None, False  # the new library handle has no callback yet
         if getattr(self, "_keep_activations", False):
             _lib.check(self._lib.vy_net_set_keep_activations(self._h, 1))
+        if getattr(self, "_conv_mode", "exact") != "exact":
+            self.set_conv_mode(self._conv_mode)
         for k, v in new_vals.items():
             self._params[k].set_data(v)
         if device is not None:
@@ -698,6 +730,7 @@ class YOLOV3(object):
         torch = _torch()
         with torch.cuda.device(self._device):
             _lib.check(self._lib.vy_net_sgd_step(self._h, lr, momentum, wd, rescale_grad, self._stream()))
+        self._params_written()
 
     def detect(self, x, return_index=False):
         """Inference branch of YOLOV3T.hybrid_forward (yolo3.py:1194-1206): returns
@@ -745,6 +778,8 @@ class YOLOV3(object):
                 th = ctypes.c_void_p()
                 _lib.check(self._lib.vy_net_create(len(self._classes), ctypes.byref(th)))
                 _lib.check(self._lib.vy_net_bind_params(th, ctypes.c_void_p(self._dev_params.data_ptr())))
+                if getattr(self, "_conv_mode", "exact") != "exact":
+                    _lib.check(self._lib.vy_net_set_conv_mode(th, _lib.VY_CONV_SPLIT_BF16X3))
                 # a stream of the library's own: torch's pooled streams may share the default stream's
                 # hardware queue, in which case the two launch sequences would simply alternate
                 sp = ctypes.c_void_p()

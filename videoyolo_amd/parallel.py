@@ -142,6 +142,7 @@ def sync_replicas(net, src=0):
         return False
     broadcast_(net._dev_params.view(torch.float32), src)
     net._replicas_synced = True
+    net._params_written()  # the device buffer was written behind the library's back
     return True
 
 
