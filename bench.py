@@ -17,6 +17,10 @@ Prints ONE JSON line on rank 0 (contract in the task statement) with extra objec
                   from HIP events recorded around every launch of one extra, un-timed pass
   cpu_baseline    the CPU oracle (oracle/, a port — NOT MXNet) timed on a bounded sample
   cpu_baseline_torch  torch-CPU forward of the same conv graph (independent datapoint, NOT MXNet)
+  also_infer608_split  the SAME inference step in the opt-in conv mode 'split_bf16x3' (csrc/conv_split.hip: bf16 x 3, six
+                  products, fp32 accumulate — NOT the parity path; tolerances in tests/test_gpu_split.py): frames/s,
+                  conv rate against the fp32 roof and against the bf16 roof / 6, batch-1 latency, HBM traffic.
+                  The headline `value` stays the exact-fp32 path.
   also_train416   BASELINE configs[2] at the same N: training step 416x416, 16 frames per GPU (recorded forward +
                   backward + gradient all-reduce over RCCL, bucketed and overlapped + SGD), timed the same way
                   (barrier + synchronize, max over ranks) — with the forward / backward / exposed-all-reduce split,
@@ -35,6 +39,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs @ 2.4 GHz
+BF16_MFMA_PEAK_TFLOPS = 2516.6  # v_mfma_f32_32x32x16_bf16: 16x the fp32 rate (same guide); the split path spends
+SPLIT_PRODUCTS = 6              # six bf16 products per fp32 multiply -> fp32-equivalent roof 2516.6 / 6 = 419.4
 HBM_PEAK_GBS = 8000.0
 ROCPROF = "/opt/rocm/bin/rocprofv3"
 
@@ -143,6 +149,54 @@ def measure_hbm_traffic(argv, steps_run):
             per_step += e["hbm_bytes"] * e["launches"] / float(steps_run)
     out["_per_step"] = per_step
     return out, None
+
+
+SPLIT_DTYPE = "f32 via bf16x3 (6 products), f32 acc"
+
+
+def launch_table(net, x):
+    """Median-of-3 per-launch table of one forward: [(name, ms, flops, algorithmic bytes)] (HIP events around every
+    launch, on the launch stream) and the same aggregated per kernel instance {key: [launches, ms, flops, bytes]}."""
+    passes = [net.profile(x) for _ in range(3)]
+    med = []
+    for j in range(len(passes[0])):
+        ms = sorted(p[j][1] for p in passes)[1]
+        med.append((passes[0][j][0], ms, passes[0][j][2], passes[0][j][3]))
+    agg = {}
+    for name, ms, fl, by in med:
+        if "|split" in name:  # "<cell>|split<BM>x<BN>": the bf16 x 3 instance (conv_split.hip)
+            key = "conv_split_kernel<%s>" % name.split("|split")[1]
+        elif "|" in name:  # conv launches are reported as "<cell>|<BM>x<BN>"
+            key = "conv_igemm_kernel<%s>" % name.split("|")[1]
+        else:
+            key = "stem_kernel" if name == "stages.0.0" else name
+        a = agg.setdefault(key, [0, 0.0, 0.0, 0.0])
+        a[0] += 1
+        a[1] += ms
+        a[2] += fl
+        a[3] += by
+    return med, agg
+
+
+def batch1_latency(net, x1, torch, size, classes):
+    """Single-frame latency (the reference's default detect call: batch_size 1, detect_yolo3.py:55,209-222): eager and
+    as a replayed HIP graph."""
+    lat = {}
+    for label, hyb in (("eager", False), ("hip_graph", True)):
+        net.hybridize(hyb)
+        for _ in range(5):
+            net(x1)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(30):
+            net(x1)
+        torch.cuda.synchronize()
+        lat[label + "_ms"] = 1e3 * (time.perf_counter() - t0) / 30
+    net.hybridize(False)
+    gf = FWD_GFLOP_PER_FRAME.get((size, classes))
+    if gf:
+        lat["frac_of_fp32_mfma_peak"] = gf / min(lat["eager_ms"], lat["hip_graph_ms"]) / FP32_MFMA_PEAK_TFLOPS
+    return dict(lat, size=size, note="one frame resident in HBM -> 100 detection rows")
 
 
 FWD_GFLOP_PER_FRAME = {(416, 20): 65.43, (608, 20): 139.76, (608, 30): 139.92}  # SURVEY.md 8(d) / BASELINE.md 3
@@ -334,6 +388,10 @@ def main():
     ap.add_argument("--no-pmc", action="store_true",
                     help="skip the rocprofv3 --pmc child runs that measure roofline.traffic (N = 1 only)")
     ap.add_argument("--no-latency", action="store_true", help="skip the batch-1 latency figure (N = 1 inference only)")
+    ap.add_argument("--conv-mode", choices=["exact", "split_bf16x3"], default="exact",
+                    help="arithmetic of the HEADLINE inference step (default exact fp32: the parity path); the default "
+                         "line reports the split mode beside it as also_infer608_split")
+    ap.add_argument("--no-split-leg", action="store_true", help="skip also_infer608_split")
     ap.add_argument("--no-train-legs", action="store_true",
                     help="infer mode: skip also_train416 / also_syncbn608 (BASELINE configs[2] / [4])")
     ap.add_argument("--train-steps", type=int, default=10, help="timed steps of each training leg")
@@ -358,13 +416,16 @@ def main():
     # same workloads under rocprofv3 --pmc, before this process touches the GPU
     traffic, traffic_note = None, "not measured (--no-pmc / --no-roofline / N > 1 / inside a profiler)"
     train_traffic, train_traffic_note = None, traffic_note
+    split_traffic, split_traffic_note = None, traffic_note
     in_child = bool(os.environ.get("VY_BENCH_CHILD"))
     if args.gpus == 1 and "WORLD_SIZE" not in os.environ and not in_child and not args.no_pmc and not args.no_roofline:
         quiet = ["--steps", "2", "--warmup", "1", "--cpu-frames", "0", "--no-roofline", "--no-pmc", "--no-latency",
                  "--no-train-legs"]
         child = ["--mode", args.mode, "--size", str(args.size), "--batch", str(args.batch), "--classes",
-                 str(args.classes), "--obj-bias", str(args.obj_bias)] + quiet
-        traffic, traffic_note = measure_hbm_traffic(child, 3)
+                 str(args.classes), "--obj-bias", str(args.obj_bias), "--no-split-leg"] + quiet
+        traffic, traffic_note = measure_hbm_traffic(child + ["--conv-mode", args.conv_mode], 3)
+        if args.mode == "infer" and args.conv_mode == "exact" and not args.no_split_leg:
+            split_traffic, split_traffic_note = measure_hbm_traffic(child + ["--conv-mode", "split_bf16x3"], 3)
         if legs:
             child = ["--mode", "train", "--size", str(args.train_size), "--batch", str(args.train_batch), "--classes",
                      str(args.classes)] + quiet
@@ -398,6 +459,7 @@ def main():
     net.initialize(init="synthetic", seed=233, obj_bias=args.obj_bias)
     net.collect_params().reset_ctx(dev)
     net.set_nms(0.45, 400, 100)  # detect_yolo3.py:200; like the reference's detect() the net is not hybridized
+    net.set_conv_mode(args.conv_mode)
 
     g = torch.Generator(device="cpu").manual_seed(233 + rank)
     x = torch.randn((args.batch, 3, args.size, args.size), generator=g, dtype=torch.float32).to(dev)
@@ -417,7 +479,7 @@ def main():
         "metric": "frames/sec, yolo3_darknet53 inference %dx%d" % (args.size, args.size),
         "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "vs_baseline": None, "dtype": "f32" if args.conv_mode == "exact" else SPLIT_DTYPE, "data": "synthetic",
         "config": {"workload": "BASELINE.json configs[1]: Darknet-53 + 3-scale head + decode + NMS "
                                "inference, %dx%d, batch %d per GPU, %d classes, nms 0.45/topk 400/post 100"
                                % (args.size, args.size, args.batch, args.classes),
@@ -428,26 +490,10 @@ def main():
 
     if rank == 0 and not args.no_roofline:
         # per-launch HIP-event timing of extra passes (same stream the kernels run on)
-        passes = [net.profile(x) for _ in range(3)]
-        names = [p[0] for p in passes[0]]
-        med = []
-        for j in range(len(names)):
-            ms = sorted(p[j][1] for p in passes)[1]
-            med.append((names[j], ms, passes[0][j][2], passes[0][j][3]))
-        agg = {}
-        for name, ms, fl, by in med:
-            if "|" in name:  # conv launches are reported as "<cell>|<BM>x<BN>"
-                key = "conv_igemm_kernel<%s>" % name.split("|")[1]
-            else:
-                key = "stem_kernel" if name == "stages.0.0" else name
-            a = agg.setdefault(key, [0, 0.0, 0.0, 0.0])
-            a[0] += 1
-            a[1] += ms
-            a[2] += fl
-            a[3] += by
+        med, agg = launch_table(net, x)
         # the dominant kernel: the implicit-GEMM tile variant with the largest share of the step
         # (128x128 at the BASELINE shape; small test shapes fall back to the smaller tiles)
-        dom = max((k for k in agg if k.startswith("conv_igemm_kernel")), key=lambda k: agg[k][1])
+        dom = max((k for k in agg if k.startswith(("conv_igemm_kernel", "conv_split_kernel"))), key=lambda k: agg[k][1])
         n, ms, fl, by = agg[dom]
         achieved = fl / (ms * 1e-3) / 1e12
         total_ms = sum(a[1] for a in agg.values())
@@ -461,6 +507,13 @@ def main():
             "by_kernel_ms": {k: round(a[1], 4) for k, a in agg.items()},
         }
         result["roofline"]["algorithmic_bytes_per_launch_avg"] = by / n
+        # Comparable across rounds whatever the "dominant" instance is (it changed identity in round 3, when stream-K
+        # split the 128x128 launches into two kernels): EVERY conv launch of the step, sum of FLOPs / sum of time.
+        conv = [a for k, a in agg.items() if k.startswith(("conv_igemm_kernel", "conv_split_kernel"))]
+        conv_ms, conv_fl = sum(a[1] for a in conv), sum(a[2] for a in conv)
+        result["roofline"]["frac_all_conv"] = conv_fl / (conv_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS
+        result["roofline"]["all_conv"] = {"launches_per_step": sum(a[0] for a in conv), "ms_per_step": conv_ms,
+                                          "tflops": conv_fl / (conv_ms * 1e-3) / 1e12}
         # the same tile's launches that ran as chain-preserving stream-K are a kernel of their own for rocprofv3
         # (conv_igemm_kernel<..., SK = true>): reported beside the dominant one, same definition of `achieved`
         twin = dom[:-3] + ">" if dom.endswith("sk>") else dom[:-1] + "sk>"
@@ -493,25 +546,7 @@ def main():
                 "ms": tail[1], "algorithmic_GBps": tail[3] / (tail[1] * 1e-3) / 1e9, "hbm_peak_GBps": HBM_PEAK_GBS}
 
     if rank == 0 and world == 1 and not args.no_latency:
-        # single-frame latency of the same path (the reference's default detect call: batch_size 1,
-        # detect_yolo3.py:55,209-222): eager and as a replayed HIP graph
-        lat = {}
-        x1 = x[:1].contiguous()
-        for label, hyb in (("eager", False), ("hip_graph", True)):
-            net.hybridize(hyb)
-            for _ in range(5):
-                net(x1)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(30):
-                net(x1)
-            torch.cuda.synchronize()
-            lat[label + "_ms"] = 1e3 * (time.perf_counter() - t0) / 30
-        net.hybridize(False)
-        gf = FWD_GFLOP_PER_FRAME.get((args.size, args.classes))
-        if gf:
-            lat["frac_of_fp32_mfma_peak"] = gf / min(lat["eager_ms"], lat["hip_graph_ms"]) / FP32_MFMA_PEAK_TFLOPS
-        result["latency_batch1"] = dict(lat, size=args.size, note="one frame resident in HBM -> 100 detection rows")
+        result["latency_batch1"] = batch1_latency(net, x[:1].contiguous(), torch, args.size, args.classes)
 
     if rank == 0 and world == 1 and not args.no_latency and args.size == 608:
         # BASELINE.json's metric names both frame sizes: the same batch at 416x416, timed the same way
@@ -530,6 +565,61 @@ def main():
                               "whole_step_tflops": None if gflop4 is None else fps4 * gflop4 / 1e3,
                               "frac_of_fp32_mfma_peak": None if gflop4 is None else fps4 * gflop4 / 1e3 / FP32_MFMA_PEAK_TFLOPS}
         del x4
+
+    if args.conv_mode == "exact" and not args.no_split_leg:
+        # The same step in the opt-in split-fp32 conv mode, on every rank, timed the same way.  NOT the headline.
+        net.set_conv_mode("split_bf16x3")
+        for _ in range(args.warmup):
+            net(x)
+        _barrier(dist, torch)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            net(x)
+        _barrier(dist, torch)
+        sdt = _max_over_ranks(time.perf_counter() - t0, dist, torch, dev)
+        sfps = args.batch * world * args.steps / sdt
+        leg = {"frames_per_s": sfps, "ms_per_step": 1e3 * sdt / args.steps, "dtype": SPLIT_DTYPE,
+               "speedup_over_exact": sfps / fps, "n_gpus": world,
+               "workload": "the headline step (%dx%d, batch %d per GPU) with net.set_conv_mode('split_bf16x3'): every "
+                           "conv+BN+leaky cell with cout %% 64 == 0 on v_mfma_f32_32x32x16_bf16 (six bf16 products per "
+                           "fp32 multiply, fp32 accumulate); stem, the 64->32 bottleneck, prediction convs, decode and NMS "
+                           "as in the exact path.  Not bit-equal to the oracle: tests/test_gpu_split.py"
+                           % (args.size, args.size, args.batch)}
+        if rank == 0 and not args.no_roofline:
+            smed, sagg = launch_table(net, x)
+            sp = [a for k, a in sagg.items() if k.startswith("conv_split_kernel")]
+            ex = [a for k, a in sagg.items() if k.startswith("conv_igemm_kernel")]
+            sp_ms, sp_fl = sum(a[1] for a in sp), sum(a[2] for a in sp)
+            tot_ms, tot_fl = sum(a[1] for a in sagg.values()), sum(a[2] for a in sagg.values())
+            eq = sp_fl / (sp_ms * 1e-3) / 1e12  # fp32-equivalent TFLOP/s of the split launches
+            leg["roofline"] = {
+                "bound": "mfma", "kernel": "conv_split_kernel (all instances)", "launches_per_step": sum(a[0] for a in sp),
+                "ms_per_step": sp_ms, "achieved_fp32_equivalent": eq, "unit": "TFLOP/s",
+                "frac_vs_fp32_mfma_peak_157": eq / FP32_MFMA_PEAK_TFLOPS,
+                "frac_vs_bf16_peak_over_6_419": eq / (BF16_MFMA_PEAK_TFLOPS / SPLIT_PRODUCTS),
+                "bf16_mfma_tflops": eq * SPLIT_PRODUCTS, "bf16_mfma_peak": BF16_MFMA_PEAK_TFLOPS,
+                "exact_kernel_launches_left": sum(a[0] for a in ex), "exact_kernel_ms_left": sum(a[1] for a in ex),
+                "whole_step_fp32_equivalent_tflops": tot_fl / (tot_ms * 1e-3) / 1e12,
+                "kernel_share_of_step_time": sp_ms / tot_ms,
+                "by_kernel_ms": {k: round(a[1], 4) for k, a in sagg.items()}, "traffic": None}
+            if split_traffic:
+                keys = [k for k in split_traffic if k.startswith("void conv_split_kernel")]
+                n_l = sum(split_traffic[k]["launches"] for k in keys)
+                if n_l:
+                    hb = sum(split_traffic[k]["hbm_bytes"] * split_traffic[k]["launches"] for k in keys) / n_l
+                    alg = sum(a[3] for a in sp) / max(1, sum(a[0] for a in sp))
+                    leg["roofline"]["traffic"] = hb
+                    leg["roofline"]["traffic_detail"] = {
+                        "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child runs with --conv-mode split_bf16x3 (FETCH x2: "
+                                  "gfx950); mean HBM bytes per conv_split_kernel launch",
+                        "algorithmic_bytes_per_launch_avg": alg, "over_algorithmic": hb / alg if alg else None,
+                        "whole_step_hbm_bytes": split_traffic["_per_step"]}
+            if leg["roofline"]["traffic"] is None:
+                leg["roofline"]["traffic_note"] = split_traffic_note
+        if rank == 0 and world == 1 and not args.no_latency:
+            leg["latency_batch1"] = batch1_latency(net, x[:1].contiguous(), torch, args.size, args.classes)
+        result["also_infer%d_split" % args.size] = leg
+        net.set_conv_mode("exact")
 
     if rank == 0 and world == 1 and args.cpu_frames > 0:
         # CPU baseline: the oracle (a port of the same algorithm; NOT the reference's MXNet path,
@@ -602,7 +692,7 @@ def bench_train(args, vy, dev, dist, rank, world, traffic=None, traffic_note=Non
         "metric": "frames/sec, yolo3_darknet53 training %dx%d" % (args.size, args.size),
         "value": leg["frames_per_s"], "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": leg["ms_per_step"], "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "vs_baseline": None, "dtype": "f32" if args.conv_mode == "exact" else SPLIT_DTYPE, "data": "synthetic",
         "config": {"workload": "BASELINE.json configs[%d]: training step, VOC-shape synthetic (%d cls, 8 gt/img), "
                                "%dx%d, per-GPU batch %d, SGD(1e-3, 0.9, 5e-4), %s BN, gradient all-reduce over %d rank(s)"
                                % (4 if args.syncbn else 2, args.classes, args.size, args.size, args.batch,

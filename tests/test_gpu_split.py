@@ -12,9 +12,15 @@ the product) are left out.  The bars here are therefore tolerances, and each is 
   boxes              <= 1e-4 * max(1, w, h)         (the bar tests/test_oracle_vs_torch.py uses between independently
                                                      ordered fp32 evaluations: exp(raw) * anchor makes the error of a
                                                      coordinate relative to the box extent)
-  NMS kept rows      identical to the oracle's on every fixture below; a fixture where a near-tie flips a row is
-                     listed in KNOWN_KEEP_EXCEPTIONS with the rows that differ (none so far)
+  NMS kept rows      identical to the oracle's on every fixture below, with ONE listed exception
+                     (KNOWN_KEEP_EXCEPTIONS): at 1 x 416 x 416 the rows 10505 and 11591, whose oracle scores are
+                     0.885419488 and 0.885419548 — ONE fp32 ulp apart — come out in the other order (output slots 84 and
+                     85 swapped; the SET of kept rows is identical).  No arithmetic that is not bit-equal to the oracle's
+                     can promise the order of two scores one ulp apart; the exception is checked, not waved through: the
+                     set must match and every displaced row's oracle score must lie within 2e-7 of its neighbour's.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -22,9 +28,17 @@ from conftest import frames
 
 pytestmark = pytest.mark.gpu
 
+
+@pytest.fixture(autouse=True)
+def _every_supported_launch_on_the_split_kernel(monkeypatch):
+    """The product sends a launch to the split kernel only where its cost model predicts a gain (large launches: the
+    test shapes here are far too small).  The parity tests force every supported launch onto it."""
+    monkeypatch.setenv("VY_SPLIT_ALWAYS", "1")
+
 HEAD_TOL = 3e-5
 TOL = 1e-4
-KNOWN_KEEP_EXCEPTIONS = {}   # (batch, size, obj_bias) -> description; empty: kept rows identical on every fixture
+# (batch, size, obj_bias) -> the output slots where the kept row differs from the oracle's
+KNOWN_KEEP_EXCEPTIONS = {(1, 416, 0.0): [(0, 84), (0, 85)]}
 
 
 def _net(classes, params, mode="split_bf16x3", **kw):
@@ -47,13 +61,13 @@ def _split_launches(net, x):
 
 
 def test_split_mode_really_runs_the_bf16_kernel(voc_classes, synth20):
-    """The mode must change which kernel runs (35 of the 38 3x3 convs: the stem and the two 64-channel layers
-    of stage 0 stay exact), and must not be bit-equal to the exact path by accident of a silent fallback."""
+    """The mode must change which kernel runs (70 of the 75 convs: all but the stem, the 64 -> 32 bottleneck and the three
+    prediction convs), and must not be bit-equal to the exact path by accident of a silent fallback."""
     x = frames(2, 96)
     net = _net(voc_classes, synth20)
     names = _split_launches(net, x)
     n_split = sum("|split" in n for n in names)
-    assert n_split == 35, names
+    assert n_split == 70, names
     net(x)
     h_split = [net.read_head(i).cpu().numpy() for i in range(3)]
     net.set_conv_mode("exact")
@@ -116,7 +130,15 @@ def test_split_detections_match_oracle(voc_classes, batch, size, obj_bias, capsy
         print("\n[split det %dx%d^2 bias %g] kept rows identical: %s; max |score diff| %.2e" %
               (batch, size, obj_bias, same, float(np.abs(scores - r_scores).max())))
     if (batch, size, obj_bias) in KNOWN_KEEP_EXCEPTIONS:
-        assert (keep == r_keep).mean() > 0.9
+        # a near-tie: the same rows, two neighbours one ulp apart in the other order
+        det = _oracle(params).detections(x)
+        diff = [tuple(int(v) for v in ij) for ij in np.argwhere(keep != r_keep)]
+        assert set(diff) <= set(KNOWN_KEEP_EXCEPTIONS[(batch, size, obj_bias)]), diff
+        for b in range(batch):
+            assert sorted(keep[b].tolist()) == sorted(r_keep[b].tolist())
+        for b, j in diff:
+            assert abs(float(det[b, keep[b, j], 1]) - float(det[b, r_keep[b, j], 1])) <= 2e-7
+        np.testing.assert_allclose(scores, r_scores, rtol=0, atol=TOL)
         return
     assert same, "NMS kept-row indices differ: %s" % np.argwhere(keep != r_keep)[:10].tolist()
     assert np.array_equal(ids, r_ids)
@@ -126,6 +148,22 @@ def test_split_detections_match_oracle(voc_classes, batch, size, obj_bias, capsy
     ext = np.maximum(1.0, np.maximum(r_bboxes[..., 2] - r_bboxes[..., 0], r_bboxes[..., 3] - r_bboxes[..., 1]))
     err = np.where(fin, np.abs(bboxes - r_bboxes), 0.0).max(-1)
     assert (err <= TOL * ext).all(), float((err / ext).max())
+
+
+def test_default_policy_keeps_small_launches_exact(voc_classes, synth20, monkeypatch):
+    """Without VY_SPLIT_ALWAYS the per-launch cost model decides (csrc/conv_cost_model.h): a single 416 x 416 frame
+    is all small launches — hardly any goes to the split kernel (a lone 128 x 128 block per CU loses to the exact
+    kernel's 64 x 64 tiles) — while 16 frames send most 3x3 layers there.  Either way the result obeys the bars."""
+    monkeypatch.delenv("VY_SPLIT_ALWAYS")
+    net = _net(voc_classes, synth20)
+    n1 = sum("|split" in n for n in _split_launches(net, frames(1, 416)))
+    x16 = frames(16, 416, seed=3)
+    n16 = sum("|split" in n for n in _split_launches(net, x16))
+    assert n1 < n16 and n1 <= 20 and n16 >= 40, (n1, n16)
+    net(x16[:2])
+    ref = _oracle(synth20).raw_heads(x16[:2])
+    for i in range(3):
+        assert np.abs(net.read_head(i).cpu().numpy() - ref[i]).max() <= HEAD_TOL
 
 
 def test_split_30_classes_and_nms_settings():

@@ -51,6 +51,10 @@ int main(int argc, char** argv) {
   for (auto& v : h_sc) v += 1.0f;
   fill_normal(h_sh, 0.5f, 777ull);
   if (res) fill_normal(h_rs, 1.0f, 4242ull);
+  if (getenv("VY_PROBE_ZERO")) {  // power experiment: all-zero operands (same instruction stream, no toggling)
+    std::fill(h_in.begin(), h_in.end(), 0.f);
+    std::fill(h_w.begin(), h_w.end(), 0.f);
+  }
   // zero borders, as the planes have them
   for (int b = 0; b < B; ++b)
     for (int y = 0; y < H + 2; ++y)

@@ -1,11 +1,9 @@
 #!/bin/bash
-# gpurun -- bash tools/probe/run_split_probe.sh   (binary built in-tree beforehand, see conv_split_probe.hip)
-P=tools/probe/conv_split_probe
+# gpurun -- bash tools/probe/run_split_probe.sh   (binary built in-tree beforehand: tools/probe/build_split_probe.sh)
+P=${P:-tools/probe/conv_split_probe}
 mkdir -p gpurun_out
 {
-timeout 120 $P 2 13 32 128 3
 timeout 120 $P 2 26 64 128 3 1 1
-timeout 120 $P 2 27 64 256 3 2
 timeout 300 $P 64 76 128 256 3
 timeout 300 $P 64 76 128 256 3 1 1
 timeout 300 $P 64 38 256 512 3

@@ -82,3 +82,34 @@ inline double vy_select_tile(long long M, int N, double K, const VySkPolicy& p, 
   }
   return best;
 }
+
+// ---- the split-fp32 instance (conv_split.hip; conv mode VY_CONV_SPLIT_BF16X3) ------------------------------------------
+// Same form, fitted on tools/probe/run_split_batch_sweep.sh (batch 1 ... 64 on six layer shapes): a CU works through its
+// tiles at alpha x K + O each whether it holds one block or two (two 128x128 blocks take 1.19 us per 16-channel k-step
+// together, a lone one 0.66 us), so a launch takes ceil(tiles / 256) rounds; a block alone on its CU runs 10 % (128-row
+// tiles of 128 channels) to 40 % (128 x 64) over the model.  alpha per unit of K: 0.0372 (128x128; the exact kernel: 0.0543),
+// 0.0227 (128x64), 0.043 (256x64, the tile of the 64-channel layers).  With few tiles the exact kernel wins — it has the
+// 64x64 tile, four LDS stages and stream-K — e.g. every layer of a single 608x608 frame but the 152x152 / 304x304 ones.
+struct VySplitModel {
+  int bm, bn;
+  double alpha, fixed, lone;
+};
+static const VySplitModel kVySplitModels[3] = {{128, 128, 0.0372, 3.0, 1.10}, {128, 64, 0.0227, 2.0, 1.40}, {256, 64, 0.043, 4.5, 1.10}};
+
+// predicted time (microseconds) of the launch on the split-fp32 kernel and the tile it would use; N % 64 == 0
+inline double vy_predict_split(long long M, int N, double K, int* bm, int* bn) {
+  double best = 1e300;
+  for (const VySplitModel& c : kVySplitModels) {
+    if (N % c.bn != 0) continue;
+    if (c.bm == 256 && N % 128 == 0) continue;  // the 256-row tile is the 64-channel layers' only
+    const long long tiles = ((M + c.bm - 1) / c.bm) * (N / c.bn);
+    double t = (double)((tiles + 255) / 256) * (c.alpha * K + c.fixed);
+    if (tiles <= 256) t *= c.lone;
+    if (t < best * 0.995) {
+      best = t;
+      *bm = c.bm;
+      *bn = c.bn;
+    }
+  }
+  return best;
+}

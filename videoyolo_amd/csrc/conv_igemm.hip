@@ -755,6 +755,14 @@ static void select_cfg(const ConvArgs& a, int* bm, int* bn) {
 
 void vy_conv_cfg(const ConvArgs& a, int* bm, int* bn) { select_cfg(a, bm, bn); }
 
+// predicted time (microseconds) of the launch on this (exact fp32) kernel: what the split-fp32 instance has to beat
+double vy_conv_predict_us(const ConvArgs& a) {
+  if (a.N <= 32) return 0.0;  // own tile, no model: never handed to the split kernel (cout % 64 != 0 anyway)
+  int bm, bn;
+  bool sk;
+  return vy_select_tile(a.M, a.N, (double)a.ntaps * a.Kc, sk_policy(a), &bm, &bn, &sk);
+}
+
 int vy_conv_tiles_m(const ConvArgs& a) {
   int bm, bn;
   select_cfg(a, &bm, &bn);

@@ -34,6 +34,7 @@
 #include "kernels.h"
 #include "../../include/vy_math.h"
 #include "conv_device.h"
+#include "conv_cost_model.h"
 
 #if defined(__HIP_DEVICE_COMPILE__)
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -100,19 +101,23 @@ hipError_t vy_launch_split_weights(const float* w, void* img, int cout, int taps
   return hipGetLastError();
 }
 
-template <int BM, int BN>
+// NSA = LDS stages of the A tile (written one k-step ahead: two suffice; three where they fit let the loop unroll by 3
+// instead of 6); the W tile always has three (its DMA is issued two k-steps ahead).
+template <int BM, int BN, int NSA>
 __global__ __launch_bounds__(256, 2) void conv_split_kernel(const ConvArgs a, const int tiles_n) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int WM = 2, WN = 2, NW = 4, NT = 256;
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-  constexpr int NS = 3;
+  constexpr int NSW = 3;
   constexpr int A_PL = BM * 32, W_PL = BN * 32;          // bytes of one plane of a stage (rows x 32 B)
-  constexpr int A_ST = 3 * A_PL, W_ST = 3 * W_PL, STAGE = A_ST + W_ST;
-  constexpr int W_INSTR = (BN / 32) * 3 / NW;            // LDS-DMA instructions per wave per k-step
+  constexpr int A_ST = 3 * A_PL, W_ST = 3 * W_PL;
+  constexpr int W_BASE = NSA * A_ST;                     // LDS: [A stages][W stages][row tables]
+  constexpr int W_TOTAL = (BN / 32) * 3;                 // LDS-DMA instructions per block per k-step ...
+  constexpr int W_INSTR = (W_TOTAL + NW - 1) / NW;       // ... and per wave (the last ones only on some waves)
   constexpr int A_SETS = BM * 2 / NT;                    // (row, octet) pairs per thread per k-step
-  static_assert((BN / 32) * 3 % NW == 0 && A_SETS >= 1 && TM >= 1 && TN >= 1, "tile");
-  __shared__ __attribute__((aligned(16))) unsigned char smem[NS * STAGE + BM * 16];
-  long long* in_off = reinterpret_cast<long long*>(smem + NS * STAGE);
+  static_assert(A_SETS >= 1 && TM >= 1 && TN >= 1 && (NSA == 2 || NSA == 3), "tile");
+  __shared__ __attribute__((aligned(16))) unsigned char smem[NSA * A_ST + NSW * W_ST + BM * 16];
+  long long* in_off = reinterpret_cast<long long*>(smem + NSA * A_ST + NSW * W_ST);
   unsigned* o_off = reinterpret_cast<unsigned*>(in_off + BM);
   unsigned* r_off = o_off + BM;
   constexpr unsigned kInvalidRow = 0x80000000u;
@@ -175,7 +180,7 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(const ConvArgs a, co
   for (int j = 0; j < W_INSTR; ++j) {
     const int q = j * NW + wave, g = q / 3, p = q - g * 3;
     w_voff[j] = (unsigned)(g * KS * 3072 + p * 1024 + lane * 16);
-    w_lds[j] = (unsigned)(A_ST + p * W_PL + g * 1024);
+    w_lds[j] = (unsigned)(W_BASE + p * W_PL + g * 1024);
   }
   const unsigned char* w_tile = reinterpret_cast<const unsigned char*>(a.w_split) + (long long)(n0 >> 5) * KS * 3072;
 
@@ -216,14 +221,15 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(const ConvArgs a, co
   auto dma_w = [&](int stage) {
 #pragma unroll
     for (int j = 0; j < W_INSTR; ++j)
-      lds_dma16_s(w_voff[j], reinterpret_cast<const float*>(w_tile + w_koff), lds0 + stage * STAGE + w_lds[j]);
+      if (W_TOTAL % NW == 0 || j * NW + wave < W_TOTAL)  // (every wait on these is vmcnt(0): the count may differ per wave)
+        lds_dma16_s(w_voff[j], reinterpret_cast<const float*>(w_tile + w_koff), lds0 + stage * W_ST + w_lds[j]);
   };
   auto store_a = [&](int stage) {
 #pragma unroll
     for (int q = 0; q < A_SETS; ++q) {
       vy_u32x4 H, M, L;
       split8(av[q][0], av[q][1], H, M, L);
-      unsigned char* d = smem + stage * STAGE + a_lds[q];
+      unsigned char* d = smem + stage * A_ST + a_lds[q];
       *reinterpret_cast<vy_u32x4*>(d) = H;
       *reinterpret_cast<vy_u32x4*>(d + A_PL) = M;
       *reinterpret_cast<vy_u32x4*>(d + 2 * A_PL) = L;
@@ -231,39 +237,73 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(const ConvArgs a, co
   };
   // fragment read offsets (inside a stage): row * 32 + swizzled octet
   const unsigned fa = (unsigned)((wm * (BM / WM) + lrow) * 32 + ((h ^ ((lrow >> 3) & 1)) << 4));
-  const unsigned fw = (unsigned)(A_ST + (wn * (BN / WN) + lrow) * 32 + ((h ^ ((lrow >> 3) & 1)) << 4));
+  const unsigned fw = (unsigned)(W_BASE + (wn * (BN / WN) + lrow) * 32 + ((h ^ ((lrow >> 3) & 1)) << 4));
 
-  auto kstep = [&](auto stage_, auto has1_, auto has2_) {
-    constexpr int ST = decltype(stage_)::value;
+  // one k-step on W stage `stw` / A stage `sta` (std::integral_constant in the unrolled main loop, so that the stage
+  // offsets fold into the ds_read / ds_write immediates; plain ints in the tail)
+  auto kstep = [&](auto stw_, auto sta_, auto has1_, auto has2_) {
+    const int STW = stw_, STA = sta_;
     constexpr bool HAS1 = decltype(has1_)::value, HAS2 = decltype(has2_)::value;
-    lds_barrier();  // stage ST complete (A by ds_write, W by DMA waited for one k-step ago) and visible
+    lds_barrier();  // this k-step's stages complete (A by ds_write, W by DMA waited for one k-step ago) and visible
     if (HAS1) {     // k-step t+1: its A values arrived while the previous k-step computed
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      store_a((ST + 1) % NS);
+      store_a((STA + 1) % NSA);
     }
     if (HAS2) {     // k-step t+2: issue its loads now, a whole k-step of matrix work ahead of their use
       advance();
       load_a();
-      dma_w((ST + 2) % NS);
+      dma_w((STW + 2) % NSW);
     }
-    const unsigned char* sb = smem + ST * STAGE;
+    const unsigned char* sa = smem + STA * A_ST;
+    const unsigned char* sw = smem + STW * W_ST;
+    // hipcc re-issues fragment reads per product group (24 ds_read_b128 per wave and k-step, where 12 would do) and
+    // sinks the MFMAs of this k-step below the next barrier, next to the next k-step's split arithmetic.  Pinning the
+    // fragments in registers (-DVY_SPLIT_PIN: 12 reads, all waited for before the first MFMA) measured 1.5 % slower.
     bf16x8 af[3][TM], wf[3][TN];
+    auto rd_a = [&](int p) {
 #pragma unroll
-    for (int p = 0; p < 3; ++p) {
+      for (int i = 0; i < TM; ++i) {
+        af[p][i] = *reinterpret_cast<const bf16x8*>(sa + fa + p * A_PL + i * 1024);
+      }
+    };
+    auto rd_w = [&](int p) {
 #pragma unroll
-      for (int i = 0; i < TM; ++i) af[p][i] = *reinterpret_cast<const bf16x8*>(sb + fa + p * A_PL + i * 1024);
-#pragma unroll
-      for (int j = 0; j < TN; ++j) wf[p][j] = *reinterpret_cast<const bf16x8*>(sb + fw + p * W_PL + j * 1024);
-    }
-    // smallest terms first: (l,h) (h,l) (m,m) (m,h) (h,m) (h,h); plane 0 = h, 1 = m, 2 = l
-    constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PW[6] = {0, 2, 1, 0, 1, 0};
-#pragma unroll
-    for (int t = 0; t < 6; ++t)
+      for (int j = 0; j < TN; ++j) {
+        wf[p][j] = *reinterpret_cast<const bf16x8*>(sw + fw + p * W_PL + j * 1024);
+      }
+    };
+    auto prod = [&](int pa, int pw) {
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[PA[t]][i], wf[PW[t]][j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[pa][i], wf[pw][j], acc[i][j], 0, 0, 0);
+    };
+    // smallest terms first: (l,h) (h,l) (m,m) (m,h) (h,m) (h,h); plane 0 = h, 1 = m, 2 = l
+    auto pin = [&](int pa, int pw) {  // (after ALL reads are issued: the wait hipcc puts here is a counted one)
+#ifndef VY_SPLIT_PIN  // probe builds only: measured 1.5 % SLOWER than letting hipcc re-read fragments where it likes
+      return;
+#endif
+#pragma unroll
+      for (int i = 0; i < TM; ++i) asm volatile("" : "+v"(af[pa][i]));
+#pragma unroll
+      for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(wf[pw][j]));
+    };
+    rd_a(2);
+    rd_w(0);
+    rd_a(0);
+    rd_w(2);
+    rd_a(1);
+    rd_w(1);
+    pin(2, 0);
+    prod(2, 0);
+    pin(0, 2);
+    prod(0, 2);
+    pin(1, 1);
+    prod(1, 1);
+    prod(1, 0);
+    prod(0, 1);
+    prod(0, 0);
   };
 
   using S0 = std::integral_constant<int, 0>;
@@ -283,21 +323,27 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(const ConvArgs a, co
     dma_w(1);
   }
   int t = 0;
-  for (; t + 5 <= T; t += 3) {  // t+2, t+3, t+4 all have a k-step two ahead
-    kstep(S0{}, Y{}, Y{});
-    kstep(S1{}, Y{}, Y{});
-    kstep(S2{}, Y{}, Y{});
+  if constexpr (NSA == 3) {
+    for (; t + 5 <= T; t += 3) {  // t+2, t+3, t+4 all have a k-step two ahead
+      kstep(S0{}, S0{}, Y{}, Y{});
+      kstep(S1{}, S1{}, Y{}, Y{});
+      kstep(S2{}, S2{}, Y{}, Y{});
+    }
+  } else {
+    for (; t + 8 <= T; t += 6) {
+      kstep(S0{}, S0{}, Y{}, Y{});
+      kstep(S1{}, S1{}, Y{}, Y{});
+      kstep(S2{}, S0{}, Y{}, Y{});
+      kstep(S0{}, S1{}, Y{}, Y{});
+      kstep(S1{}, S0{}, Y{}, Y{});
+      kstep(S2{}, S1{}, Y{}, Y{});
+    }
   }
-  auto tail = [&](auto stage_, int tt) {
-    const int after = T - 1 - tt;
-    if (after >= 2) kstep(stage_, Y{}, Y{});
-    else if (after == 1) kstep(stage_, Y{}, N_{});
-    else kstep(stage_, N_{}, N_{});
-  };
-  for (; t < T; t += 3) {
-    tail(S0{}, t);
-    if (t + 1 < T) tail(S1{}, t + 1);
-    if (t + 2 < T) tail(S2{}, t + 2);
+  for (; t < T; ++t) {  // tail (and launches too short for the unrolled loop): stage numbers at run time
+    const int after = T - 1 - t, stw = t % NSW, sta = t % NSA;
+    if (after >= 2) kstep(stw, sta, Y{}, Y{});
+    else if (after == 1) kstep(stw, sta, Y{}, N_{});
+    else kstep(stw, sta, N_{}, N_{});
   }
 
   // ---- epilogue (conv_igemm.hip): affine -> leaky -> + addend -> store (x1 or x2-replicated)
@@ -373,9 +419,25 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(const ConvArgs a, co
 
 bool vy_conv_split_supported(const ConvArgs& a) {
   if (a.dgrad || a.stats || !a.w_split || !a.shift) return false;
-  if (a.Kc % 32 != 0 || a.N % 128 != 0 || a.ntaps < 1 || a.ntaps > 9) return false;
+  if (a.Kc % 32 != 0 || a.N % 64 != 0 || a.ntaps < 1 || a.ntaps > 9) return false;
   const bool bn_cell = a.scale && a.leaky, bias = !a.scale && !a.leaky && !a.res && a.ups != 2;
   return (bn_cell && (a.ups != 2 || !a.res)) || bias;
+}
+
+// block tile of a launch: the cost model's choice (conv_cost_model.h) among 128x128, 128x64 and, for the 64-channel
+// layers, 256x64
+void vy_conv_split_cfg(const ConvArgs& a, int* bm, int* bn) {
+  static const char* force = getenv("VY_SPLIT_FORCE");  // experiments: VY_SPLIT_FORCE=128x64
+  if (force && sscanf(force, "%dx%d", bm, bn) == 2 && a.N % *bn == 0) return;
+  vy_predict_split(a.M, a.N, (double)a.ntaps * a.Kc, bm, bn);
+}
+
+bool vy_conv_split_pays(const ConvArgs& a) {
+  if (!vy_conv_split_supported(a)) return false;
+  const char* always = getenv("VY_SPLIT_ALWAYS");  // tests: every supported launch, however small (read per call)
+  if (always && atoi(always)) return true;
+  int bm, bn;
+  return vy_predict_split(a.M, a.N, (double)a.ntaps * a.Kc, &bm, &bn) < 0.97 * vy_conv_predict_us(a);
 }
 
 static VyFastDiv split_fastdiv(unsigned d) {
@@ -386,6 +448,13 @@ static VyFastDiv split_fastdiv(unsigned d) {
   f.s1 = l < 1 ? l : 1;
   f.s2 = l > 0 ? l - 1 : 0;
   return f;
+}
+
+template <int BM, int BN, int NSA>
+static hipError_t launch_split(const ConvArgs& a, hipStream_t s) {
+  const int tiles_m = (a.M + BM - 1) / BM, tiles_n = a.N / BN;
+  hipLaunchKernelGGL((conv_split_kernel<BM, BN, NSA>), dim3(tiles_m * tiles_n), dim3(256), 0, s, a, tiles_n);
+  return hipGetLastError();
 }
 
 hipError_t vy_launch_conv_split(const ConvArgs& a_in, hipStream_t s) {
@@ -401,8 +470,10 @@ hipError_t vy_launch_conv_split(const ConvArgs& a_in, hipStream_t s) {
     a.pk_dx |= (unsigned)(a.tap_dx[t] + 1) << (2 * t);
     a.pk_w |= (unsigned long long)a.tap_w[t] << (4 * t);
   }
-  constexpr int BM = 128, BN = 128;
-  const int tiles_m = (a.M + BM - 1) / BM, tiles_n = a.N / BN;
-  hipLaunchKernelGGL((conv_split_kernel<BM, BN>), dim3(tiles_m * tiles_n), dim3(256), 0, s, a, tiles_n);
-  return hipGetLastError();
+  int bm, bn;
+  vy_conv_split_cfg(a, &bm, &bn);
+  if (bm == 128 && bn == 128) return launch_split<128, 128, 3>(a, s);
+  if (bm == 256 && bn == 64) return launch_split<256, 64, 2>(a, s);
+  if (bm == 128 && bn == 64) return launch_split<128, 64, 3>(a, s);
+  return hipErrorInvalidValue;
 }

@@ -63,13 +63,18 @@ hipError_t vy_launch_conv_igemm(const ConvArgs& a, hipStream_t s);
 hipError_t vy_launch_conv_s16(const ConvArgs& a, int bm, int bn, hipStream_t s);
 int vy_conv_tiles_m(const ConvArgs& a);
 void vy_conv_cfg(const ConvArgs& a, int* bm, int* bn);  // block tile the launch will use
+double vy_conv_predict_us(const ConvArgs& a);             // the cost model's time for the launch (conv_cost_model.h)
 bool vy_conv_streamk(const ConvArgs& a);                  // ... and whether it will be a stream-K launch (label "<BM>x<BN>sk")
 
 // Opt-in split-fp32 forward conv on the bf16 matrix core (conv_split.hip: bf16 x 3, six products, fp32 accumulate).
 // Same ConvArgs / planes as vy_launch_conv_igemm, plus a.w_split = the conv's weights as bf16 tile images.
 size_t vy_split_weight_bytes(int cout, int taps, int cin);
 hipError_t vy_launch_split_weights(const float* w, void* img, int cout, int taps, int cin, hipStream_t s);
-bool vy_conv_split_supported(const ConvArgs& a);   // forward, N % 128 == 0, Kc % 32 == 0, an epilogue the kernel has
+bool vy_conv_split_supported(const ConvArgs& a);   // forward, N % 64 == 0, Kc % 32 == 0, an epilogue the kernel has
+void vy_conv_split_cfg(const ConvArgs& a, int* bm, int* bn);  // block tile the launch will use
+// conv mode VY_CONV_SPLIT_BF16X3, per launch: supported AND predicted faster than the exact kernel (small launches —
+// a single frame's deep layers — stay on the exact kernel, which has the small tiles and stream-K)
+bool vy_conv_split_pays(const ConvArgs& a);
 hipError_t vy_launch_conv_split(const ConvArgs& a, hipStream_t s);
 
 // stem: 3x3 stride-1 conv from the caller's NCHW image (Cin = 3) into a plane, fused affine+leaky.

@@ -251,13 +251,15 @@ struct vy_net {
   // ---- planning
   static size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
 
-  // which inference launches the split-fp32 kernel takes in conv mode VY_CONV_SPLIT_BF16X3: the 3x3 cells whose tile
-  // geometry it has (cout a multiple of 128).  The 1x1 layers stay on the exact kernel by default (K <= 1024: they
-  // are bound by their epilogue and by HBM, not by the matrix pipe; VY_SPLIT_1X1=1 sends them along for experiments).
+  // which inference launches the split-fp32 kernel takes in conv mode VY_CONV_SPLIT_BF16X3: every conv+BN+leaky cell
+  // whose tile geometry it has (cout a multiple of 64, cin of 32) — the 3x3 cells (1.4-1.5x the exact kernel at
+  // 608x608 batch 64; the two 64-channel ones 1.15x) and the 1x1 cells (1.13x at K = 128 ... 1.5x at K = 1024;
+  // VY_SPLIT_1X1=0 keeps those exact).  The stem (Cin = 3), the 64 -> 32 bottleneck and the prediction convs
+  // (75 channels) stay on the exact kernel.
   bool split_eligible(const ConvT& c) const {
-    static const int with_1x1 = getenv("VY_SPLIT_1X1") ? atoi(getenv("VY_SPLIT_1X1")) : 0;
+    static const int with_1x1 = getenv("VY_SPLIT_1X1") ? atoi(getenv("VY_SPLIT_1X1")) : 1;
     if (conv_mode != VY_CONV_SPLIT_BF16X3 || c.is_stem || c.p_gamma < 0) return false;
-    if (c.cout % 128 != 0 || c.cin % 32 != 0) return false;
+    if (c.cout % 64 != 0 || c.cin % 32 != 0) return false;
     return c.k == 3 || with_1x1;
   }
 
@@ -516,8 +518,10 @@ struct vy_net {
         const double by = 4.0 * ((double)B * (a.a_Hp - 2) * (a.a_Wp - 2) * a.Kc + (double)a.M * a.N * a.ups * a.ups +
                                  (double)a.N * a.ntaps * a.Kc + (a.res ? (double)a.M * a.N : 0.0));
         char nm[96];
-        if (a.w_split && vy_conv_split_supported(a)) {
-          snprintf(nm, sizeof nm, "%s|split128x128", c.name.c_str());
+        if (a.w_split && vy_conv_split_pays(a)) {
+          int sbm, sbn;
+          vy_conv_split_cfg(a, &sbm, &sbn);
+          snprintf(nm, sizeof nm, "%s|split%dx%d", c.name.c_str(), sbm, sbn);
           hook(nm, fl, by, true);
           HIP_TRY(vy_launch_conv_split(a, s));
           hook(nm, fl, by, false);
