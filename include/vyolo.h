@@ -135,6 +135,13 @@ int32_t vy_net_get_conv_mode(const vy_net* net);
  * says so with this call. */
 int vy_net_invalidate_split_weights(vy_net* net);
 
+/* Diagnostics of the chain-preserving stream-K conv launches (csrc/conv_igemm.hip; no counterpart in the reference).
+ * enabled: 1 if the bind-time probe saw the workgroup placement the schedule is built for (MI355X, SPX mode: 8 XCDs,
+ * blocks L and L + 8 on one XCD, 256 CUs) — otherwise every conv is a plain launch.  flags_offset / n_flags: where the
+ * hand-off flags live in the bound workspace (32-bit words, all zero between launches; after ANY entry point of the
+ * handle has returned an error the next forward / training step zeroes them before it launches).  Tests only. */
+int vy_net_streamk_state(const vy_net* net, int32_t* enabled, size_t* flags_offset, int32_t* n_flags);
+
 /* Number of anchors N = 3 * sum_i (H/s_i)(W/s_i) for the planned shape. */
 int32_t vy_net_num_anchors(const vy_net* net);
 

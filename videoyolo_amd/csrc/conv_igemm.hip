@@ -179,8 +179,15 @@ __device__ __forceinline__ void conv_tile(Args& a, const int tiles_n, const SkAr
     // out-of-range loads return 0.0f without touching memory — the accumulators have ONE definition (a branch here
     // made hipcc keep two copies of them: 2x the registers).
     if (load_partial && tid == 0) {
-      while (__hip_atomic_load(sk.flags + (vblk - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u)
+      // bounded: the predecessor was dispatched before this block and reaches its HEAD without waiting for anything, so
+      // the flag normally goes up within microseconds; two seconds (s_memrealtime ticks at 100 MHz) without it means the
+      // launch is broken (a faulted predecessor, a workspace shared by two streams): abort the kernel instead of hanging
+      // the queue — the host sees hipErrorLaunchFailure at its next synchronisation
+      const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+      while (__hip_atomic_load(sk.flags + (vblk - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
         __builtin_amdgcn_s_sleep(4);
+        if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) __builtin_trap();
+      }
     }
     if (load_partial) __syncthreads();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  // no instruction: keeps the loads below the poll
@@ -634,6 +641,42 @@ static int cu_count() {
     return c;
   }();
   return n;
+}
+
+// ---- stream-K topology check --------------------------------------------------------------------------------------
+// The stream-K schedule (sk_schedule.h) is built for the MI355X in SPX mode: 256 CUs, 8 XCDs, workgroups dealt round-robin
+// over the XCDs so that blocks L and L + 8 share an L2 (its locality, its cost model and its "one XCD group = one run of
+// tiles" bookkeeping all assume that).  The hand-off itself is placement-independent (write-through sc1 stores, sc1 loads:
+// MI355X_MICROARCH.md, Valid forms), but nothing else about the schedule has been measured on another partition mode, a
+// CU-masked queue or a part with fewer XCDs — so a net enables stream-K only after this probe has seen the expected
+// placement on its device: 512 one-wave blocks record their XCC id; ids must be < 8, the first eight distinct, and
+// id[b] == id[b % 8] for every b.  Otherwise the net runs plain launches (the SK scratch pointers stay null).
+__global__ void xcc_probe_kernel(unsigned* out) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  if (threadIdx.x == 0) out[blockIdx.x] = __builtin_amdgcn_s_getreg(20 | (31 << 11)) & 15u;  // HW_REG_XCC_ID
+#endif
+}
+
+int vy_sk_verify_topology(unsigned* scratch_dev, hipStream_t s) {
+  static int cache[64];  // per device: 0 unknown, 1 verified, 2 refused
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+  if (cache[dev]) return cache[dev] == 1;
+  if (getenv("VY_CONV_SK_NO_TOPOLOGY_CHECK") && atoi(getenv("VY_CONV_SK_NO_TOPOLOGY_CHECK"))) return (cache[dev] = 1) == 1;
+  constexpr int NB = 512;
+  unsigned host[NB];
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return 0;  // decided outside a capture
+  hipLaunchKernelGGL(xcc_probe_kernel, dim3(NB), dim3(64), 0, s, scratch_dev);
+  bool ok = hipGetLastError() == hipSuccess &&
+            hipMemcpyAsync(host, scratch_dev, sizeof host, hipMemcpyDeviceToHost, s) == hipSuccess &&
+            hipMemsetAsync(scratch_dev, 0, sizeof host, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
+  ok = ok && cu_count() == 256;  // the cost model's rounds and the schedule's shares are per 256 CUs
+  for (int b = 0; ok && b < NB; ++b) ok = host[b] < 8u && host[b] == host[b & 7];
+  for (int i = 0; ok && i < 8; ++i)
+    for (int j = 0; j < i; ++j) ok = ok && host[i] != host[j];
+  cache[dev] = ok ? 1 : 2;
+  return ok;
 }
 
 // ---- the launch cost model (conv_cost_model.h), shared by the tile choice (select_cfg) and the stream-K decision ----

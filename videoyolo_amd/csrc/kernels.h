@@ -66,6 +66,11 @@ void vy_conv_cfg(const ConvArgs& a, int* bm, int* bn);  // block tile the launch
 double vy_conv_predict_us(const ConvArgs& a);             // the cost model's time for the launch (conv_cost_model.h)
 bool vy_conv_streamk(const ConvArgs& a);                  // ... and whether it will be a stream-K launch (label "<BM>x<BN>sk")
 
+// stream-K is enabled per net only after this has seen the MI355X's SPX placement (8 XCDs, blocks L and L + 8 on one
+// XCD, 256 CUs) on the current device; `scratch_dev`: >= 512 words the probe may use and leaves zeroed.  Synchronises `s`
+// the first time it is called for a device; 0 while `s` is being captured.
+int vy_sk_verify_topology(unsigned* scratch_dev, hipStream_t s);
+
 // Opt-in split-fp32 forward conv on the bf16 matrix core (conv_split.hip: bf16 x 3, six products, fp32 accumulate).
 // Same ConvArgs / planes as vy_launch_conv_igemm, plus a.w_split = the conv's weights as bf16 tile images.
 size_t vy_split_weight_bytes(int cout, int taps, int cin);

@@ -145,6 +145,8 @@ int vy_net_bind_workspace(vy_net* net, void* dev_ws, size_t bytes, int32_t batch
   net->ws_bytes = bytes;
   net->fold_uploaded = false;
   HIP_TRY(hipMemsetAsync(dev_ws, 0, need, static_cast<hipStream_t>(stream)));
+  net->sk_dirty = false;
+  net->sk_ok = vy_sk_verify_topology(reinterpret_cast<unsigned*>(net->dev_ws + net->sk_off), static_cast<hipStream_t>(stream)) != 0;
   return 0;
 }
 
@@ -171,6 +173,15 @@ int vy_net_set_conv_mode(vy_net* net, int32_t mode) {
 
 int32_t vy_net_get_conv_mode(const vy_net* net) { return net ? net->conv_mode : 0; }
 
+int vy_net_streamk_state(const vy_net* net, int32_t* enabled, size_t* flags_offset, int32_t* n_flags) {
+  if (!net) return fail(VY_ERR_INVALID, "net is null");
+  if (!net->dev_ws) return fail(VY_ERR_STATE, "workspace not bound");
+  if (enabled) *enabled = net->sk_ok ? 1 : 0;
+  if (flags_offset) *flags_offset = net->sk_off;
+  if (n_flags) *n_flags = VY_SK_FLAGS;
+  return 0;
+}
+
 int vy_net_invalidate_split_weights(vy_net* net) {
   if (!net) return fail(VY_ERR_INVALID, "net is null");
   net->split_dirty = true;
@@ -186,9 +197,11 @@ int32_t vy_net_num_anchors(const vy_net* net) {
 
 int vy_net_forward_infer(vy_net* net, const float* x, float* ids, float* scores, float* bboxes, int32_t* keep_idx,
                          void* stream) {
+  if (net && (!x || !ids || !scores || !bboxes)) net->sk_dirty = true;  // (any error return: see vy_net::sk_dirty)
   if (!net || !x || !ids || !scores || !bboxes) return fail(VY_ERR_INVALID, "null argument");
-  return net->forward(x, ids, scores, bboxes, keep_idx, static_cast<hipStream_t>(stream),
-                      [](const char*, double, double, bool) {});
+  if (int rc = net->sk_begin(static_cast<hipStream_t>(stream))) return rc;
+  return net->sk_end(net->forward<false>(x, ids, scores, bboxes, keep_idx, static_cast<hipStream_t>(stream),
+                                         [](const char*, double, double, bool) {}));
 }
 
 int vy_net_read_head(vy_net* net, int32_t i, float* dst_dev, void* stream) {
@@ -248,7 +261,8 @@ int vy_net_profile_infer(vy_net* net, const float* x, float* ids, float* scores,
       ev1.push_back(e);
     }
   };
-  int rc = net->forward(x, ids, scores, bboxes, nullptr, s, hook);
+  int rc = net->sk_begin(s);
+  if (rc == 0) rc = net->sk_end(net->forward(x, ids, scores, bboxes, nullptr, s, hook));
   if (rc == 0) {
     hipError_t e = hipStreamSynchronize(s);
     if (e != hipSuccess) rc = fail(VY_ERR_HIP, "sync: %s", hipGetErrorString(e));

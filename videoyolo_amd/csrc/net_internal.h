@@ -78,6 +78,11 @@ struct vy_net {
   // vy_net_set_conv_mode: VY_CONV_SPLIT_BF16X3 sends the inference launches conv_split.hip can serve through the bf16
   // matrix core (bf16 x 3, six products, fp32 accumulate); their pre-split weight images live in the workspace and are
   // rebuilt by the next forward whenever the parameters may have changed (split_dirty)
+  // stream-K bookkeeping: sk_ok = the device's workgroup placement was verified at bind time (vy_sk_verify_topology);
+  // sk_dirty = an entry point of this handle returned an error after it may have launched stream-K kernels: the hand-off
+  // flags are cleared by their consumers, so an aborted sequence can leave one up — the next forward / step zeroes them
+  bool sk_ok = false;
+  bool sk_dirty = false;
   int conv_mode = 0;
   bool split_dirty = true;
   size_t wsplit_off = 0;
@@ -290,8 +295,12 @@ struct vy_net {
     std::vector<int> owners;
     for (int p : order) {
       int take = -1;
+      // a prediction plane never takes over a freed plane: its conv writes npred of the C (padded) channels and the
+      // padding must stay the zeros of the bind-time memset (80 classes: 255 -> 256 channels, the geometry of the
+      // stage-1 bottleneck planes)
+      const bool is_head = p == head_plane[0] || p == head_plane[1] || p == head_plane[2];
       for (int o : owners)
-        if (planes[o].C == planes[p].C && planes[o].div == planes[p].div && free_at[o] < def[p]) {
+        if (!is_head && planes[o].C == planes[p].C && planes[o].div == planes[p].div && free_at[o] < def[p]) {
           take = o;
           break;
         }
@@ -426,8 +435,22 @@ struct vy_net {
     return a;
   }
 
-  // the stream-K scratch of this net's workspace (zeroed with the workspace at bind time: all flags down)
+  int sk_begin(hipStream_t s) {
+    if (sk_dirty && dev_ws) {
+      HIP_TRY(hipMemsetAsync(dev_ws + sk_off, 0, al((size_t)VY_SK_FLAGS * sizeof(unsigned)), s));
+      sk_dirty = false;
+    }
+    return 0;
+  }
+  int sk_end(int rc) {
+    if (rc != 0) sk_dirty = true;
+    return rc;
+  }
+
+  // the stream-K scratch of this net's workspace (zeroed with the workspace at bind time: all flags down); left null —
+  // plain launches only — unless the device's workgroup placement was verified
   void set_sk(ConvArgs& a) const {
+    if (!sk_ok) return;
     a.sk_flags = reinterpret_cast<unsigned*>(dev_ws + sk_off);
     a.sk_partials = reinterpret_cast<float*>(dev_ws + sk_off + al((size_t)VY_SK_FLAGS * sizeof(unsigned)));
     a.sk_bytes = VY_SK_PARTIAL_BYTES;
@@ -466,7 +489,8 @@ struct vy_net {
   }
 
   // launches of one inference forward; `hook` (optional) is called around every launch
-  template <typename Hook>
+  // kLabels = false: the hook is a no-op (vy_net_forward_infer) and the per-launch labels are not built
+  template <bool kLabels = true, typename Hook>
   int forward(const float* x, float* ids, float* scores, float* bboxes, int32_t* keep_idx, hipStream_t s,
               Hook&& hook) {
     if (int rc = check_ready()) return rc;
@@ -514,6 +538,13 @@ struct vy_net {
         hook(c.name.c_str(), fl, by, false);
       } else {
         const ConvArgs a = conv_args(c);
+        if (!kLabels) {  // plain forward: no label, no second tile / stream-K query per launch (batch-1 latency path)
+          if (a.w_split && vy_conv_split_pays(a))
+            HIP_TRY(vy_launch_conv_split(a, s));
+          else
+            HIP_TRY(vy_launch_conv_igemm(a, s));
+          continue;
+        }
         const double fl = 2.0 * a.M * (double)a.N * a.ntaps * a.Kc;
         const double by = 4.0 * ((double)B * (a.a_Hp - 2) * (a.a_Wp - 2) * a.Kc + (double)a.M * a.N * a.ups * a.ups +
                                  (double)a.N * a.ntaps * a.Kc + (a.res ? (double)a.M * a.N : 0.0));

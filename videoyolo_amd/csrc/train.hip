@@ -776,6 +776,8 @@ int vy_net_bind_train(vy_net* net, void* dev_ws, size_t bytes, int32_t batch, in
   t->forward_done = false;
   hipStream_t s = static_cast<hipStream_t>(stream);
   HIP_TRY(hipMemsetAsync(dev_ws, 0, need, s));
+  net->sk_dirty = false;
+  net->sk_ok = vy_sk_verify_topology(reinterpret_cast<unsigned*>(net->dev_ws + net->sk_off), s) != 0;
   static const int use_side = getenv("VY_TRAIN_SIDE_STREAM") ? atoi(getenv("VY_TRAIN_SIDE_STREAM")) : 1;
   if (use_side && !t->side) {
     HIP_TRY(hipStreamCreateWithFlags(&t->side, hipStreamNonBlocking));
@@ -793,7 +795,7 @@ int vy_net_set_train_options(vy_net* net, float ignore_iou_thresh, int32_t label
   return 0;
 }
 
-int vy_net_train_forward(vy_net* net, const float* x, const float* gt_boxes, int32_t M, const float* obj_t,
+static int train_forward_impl(vy_net* net, const float* x, const float* gt_boxes, int32_t M, const float* obj_t,
                          const float* centers_t, const float* scales_t, const float* weights_t,
                          const float* clas_t, float* losses, void* stream) {
   if (!net || !x || !obj_t || !centers_t || !scales_t || !weights_t || !clas_t || !losses || (M > 0 && !gt_boxes))
@@ -833,7 +835,16 @@ int vy_net_train_forward(vy_net* net, const float* x, const float* gt_boxes, int
   return 0;
 }
 
-int vy_net_train_mode_forward(vy_net* net, const float* x, float* box_preds, float* centers, float* scales,
+int vy_net_train_forward(vy_net* net, const float* x, const float* gt_boxes, int32_t M, const float* obj_t,
+                         const float* centers_t, const float* scales_t, const float* weights_t,
+                         const float* clas_t, float* losses, void* stream) {
+  if (net)
+    if (int rc = net->sk_begin(static_cast<hipStream_t>(stream))) return rc;
+  const int rc = train_forward_impl(net, x, gt_boxes, M, obj_t, centers_t, scales_t, weights_t, clas_t, losses, stream);
+  return net ? net->sk_end(rc) : rc;
+}
+
+static int train_mode_forward_impl(vy_net* net, const float* x, float* box_preds, float* centers, float* scales,
                               float* objness, float* class_pred, void* stream) {
   if (!net || !x || !box_preds || !centers || !scales || !objness || !class_pred) return fail(VY_ERR_INVALID, "null argument");
   if (int rc = net->check_ready()) return rc;
@@ -863,7 +874,15 @@ int vy_net_train_mode_forward(vy_net* net, const float* x, float* box_preds, flo
   return 0;
 }
 
-int vy_net_train_backward(vy_net* net, const float* x, void* stream) {
+int vy_net_train_mode_forward(vy_net* net, const float* x, float* box_preds, float* centers, float* scales,
+                              float* objness, float* class_pred, void* stream) {
+  if (net)
+    if (int rc = net->sk_begin(static_cast<hipStream_t>(stream))) return rc;
+  const int rc = train_mode_forward_impl(net, x, box_preds, centers, scales, objness, class_pred, stream);
+  return net ? net->sk_end(rc) : rc;
+}
+
+static int train_backward_impl(vy_net* net, const float* x, void* stream) {
   if (!net || !x) return fail(VY_ERR_INVALID, "null argument");
   if (int rc = net->check_ready()) return rc;
   VyTrain* t = net->train;
@@ -871,6 +890,13 @@ int vy_net_train_backward(vy_net* net, const float* x, void* stream) {
   TrainCtx c{net, t, static_cast<hipStream_t>(stream)};
   t->forward_done = false;
   return backward_train(c, x);
+}
+
+int vy_net_train_backward(vy_net* net, const float* x, void* stream) {
+  if (net)
+    if (int rc = net->sk_begin(static_cast<hipStream_t>(stream))) return rc;
+  const int rc = train_backward_impl(net, x, stream);
+  return net ? net->sk_end(rc) : rc;
 }
 
 int vy_net_param_set_opt(vy_net* net, int32_t i, float lr_mult, float wd_mult, int32_t enabled) {
