@@ -72,11 +72,13 @@ void vy_net_destroy(vy_net* net);
 /* net.set_nms(nms_thresh, nms_topk, post_nms) — yolo3.py:1208-1228.
  *   nms_topk in [1, VY_MAX_TOPK]   the nms_topk best valid candidates go through NMS (the scripts use 400)
  *   nms_topk <= 0                  "-1 to disable": EVERY valid candidate goes through NMS (consumed in
- *                                  score order in chunks of VY_MAX_TOPK until post_nms rows are kept); needs
- *                                  post_nms in [1, VY_MAX_TOPK] — the un-sliced result would have N*C rows
- *   nms_topk > VY_MAX_TOPK         the same chunked kernel, stopped after nms_topk candidates; also needs
- *                                  post_nms in [1, VY_MAX_TOPK] (otherwise VY_ERR_UNSUPPORTED from the forward)
- *   post_nms <= 0                  the outputs have nms_topk rows (no slice, yolo3.py:1201-1202)
+ *                                  score order in chunks of VY_MAX_TOPK until the output rows are filled)
+ *   nms_topk > VY_MAX_TOPK         the same chunked kernel, stopped after nms_topk candidates
+ *   post_nms > 0                   the outputs have post_nms rows (any value; > VY_MAX_TOPK with a chunked nms_topk: the
+ *                                  kept rows are read back from the output instead of living in LDS)
+ *   post_nms <= 0                  no slice (yolo3.py:1201-1202): nms_topk rows, or — nms_topk <= 0 too — all N*C rows
+ *                                  of box_nms's un-sliced output (vy_net_num_anchors * num_class; quadratic in the worst
+ *                                  case, like the reference's loop)
  *   nms_thresh outside (0, 1)      no NMS at all: see vy_net_forward_infer */
 #define VY_MAX_TOPK 1024
 int vy_net_set_nms(vy_net* net, float nms_thresh, int32_t nms_topk, int32_t post_nms);

@@ -400,13 +400,32 @@ def test_nms_topk_disabled_uses_every_valid_candidate(voc_classes, size, post, o
     k400 = net(x, return_index=True)[3].cpu().numpy()
     if (k400 >= 0).sum() < (keep >= 0).sum():
         assert np.array_equal(k400[k400 >= 0], keep[:, :k400.shape[1]][k400 >= 0])   # a prefix of the unbounded run
-    # combinations without a bounded output are refused, loudly
-    net.set_nms(0.45, -1, -1)
-    with pytest.raises(_lib.VyError):
-        net(x)
-    net.set_nms(0.45, 2000, -1)                       # nms_topk > 1024 without a slice: 2000 output rows
-    with pytest.raises(_lib.VyError):
-        net(x)
+
+
+@pytest.mark.parametrize("topk,post", [(-1, -1), (2000, -1), (-1, 1500), (3000, 2000)])
+def test_nms_settings_with_long_outputs(voc_classes, topk, post):
+    """The set_nms combinations that used to return VY_ERR_UNSUPPORTED (yolo3.py:1208-1228 accepts them all): a chunked
+    nms_topk (<= 0: every valid candidate; > 1024) together with an output of more than 1024 rows (post_nms <= 0: no
+    slice; post_nms > 1024).  The kept rows are then read back from the output instead of one workgroup's LDS.
+    Rows: post_nms, else nms_topk, else all N*C rows of box_nms's output; kept rows exact against the oracle, whose
+    un-sliced output has N*C rows of which everything past ours is -1 filler."""
+    from videoyolo_amd import init
+    from oracle import yolo3_oracle as O
+    params = init.synthetic_params(O.param_shapes(20), seed=233)
+    x = frames(2, 96, seed=41)
+    net = _net(voc_classes, params)
+    net.set_nms(0.45, topk, post)
+    ids, scores, bboxes, keep = [t.cpu().numpy() for t in net(x, return_index=True)]
+    r = _oracle(params, nms_topk=topk, post_nms=post)(x)
+    n_cand = 3 * (3 * 3 + 6 * 6 + 12 * 12) * 20
+    rows = post if post > 0 else (topk if topk > 0 else n_cand)
+    assert ids.shape == (2, rows, 1) and bboxes.shape == (2, rows, 4)
+    assert r[3].shape[1] >= rows and (r[3][:, rows:] == -1).all()        # nothing of the oracle's result is cut off
+    assert np.array_equal(keep, r[3][:, :rows]) and np.array_equal(ids, r[0][:, :rows])
+    np.testing.assert_allclose(scores, r[1][:, :rows], rtol=0, atol=TOL)
+    fin = np.isfinite(r[2][:, :rows])
+    np.testing.assert_allclose(bboxes[fin], r[2][:, :rows][fin], rtol=0, atol=TOL)
+    assert (keep >= 0).sum(1).min() > 1024 or topk > 0, (keep >= 0).sum(1)   # the unbounded runs keep more than one chunk
 
 
 @pytest.mark.parametrize("topk,post", [(1025, 100), (2000, 400), (3000, 1024), (5000, 60)])

@@ -644,6 +644,7 @@ __global__ __launch_bounds__(kAllThreads) void nms_all_kernel(const DetArgs d, v
   __shared__ int n_kept, n_taken;
   const int n0 = d.head[0].H * d.head[0].W * 3, n1 = d.head[1].H * d.head[1].W * 3;
   const int total = d.C * n_items;
+  const bool kept_in_lds = rows <= VY_NMS_MAX_TOPK;
   // candidate row of cached score idx = c*n_items + item
   auto cand_of = [&](int idx, int& c, int& it) -> uint32_t {
     c = idx / n_items;
@@ -768,14 +769,26 @@ __global__ __launch_bounds__(kAllThreads) void nms_all_kernel(const DetArgs d, v
         __syncthreads();
       }
     }
-    // ---- suppression: first by the rows kept in earlier chunks, then greedily inside the chunk
+    // ---- suppression: first by the rows kept in earlier chunks, then greedily inside the chunk.  The kept rows live
+    // in LDS while the output has at most VY_NMS_MAX_TOPK rows; a longer output (nms_topk > 1024 or <= 0 together with
+    // post_nms <= 0 or > 1024) IS the list of kept rows, so they are read back from it (written by this workgroup,
+    // fenced at workgroup scope below)
     const int nk = n_kept;
     if (t < k) {
       const int e = perm[t];
       bool ok = true;
-      for (int j = 0; j < nk && ok; ++j)
-        if (kcls[j] == bcls[e] && vy_box_iou(kx1[j], ky1[j], kx2[j], ky2[j], bx1[e], by1[e], bx2[e], by2[e]) > d.nms_thresh)
-          ok = false;
+      if (kept_in_lds) {
+        for (int j = 0; j < nk && ok; ++j)
+          if (kcls[j] == bcls[e] && vy_box_iou(kx1[j], ky1[j], kx2[j], ky2[j], bx1[e], by1[e], bx2[e], by2[e]) > d.nms_thresh)
+            ok = false;
+      } else {
+        const float* kb = bboxes + (size_t)b * rows * 4;
+        const float* kc = ids + (size_t)b * rows;
+        for (int j = 0; j < nk && ok; ++j)
+          if (kc[j] == bcls[e] &&
+              vy_box_iou(kb[j * 4 + 0], kb[j * 4 + 1], kb[j * 4 + 2], kb[j * 4 + 3], bx1[e], by1[e], bx2[e], by2[e]) > d.nms_thresh)
+            ok = false;
+      }
       alive[t] = ok ? 1 : 0;
     }
     __syncthreads();
@@ -804,11 +817,13 @@ __global__ __launch_bounds__(kAllThreads) void nms_all_kernel(const DetArgs d, v
       const int r = nk + pos[t] - 1;
       if (r < rows) {
         const int e = perm[t];
-        kx1[r] = bx1[e];
-        ky1[r] = by1[e];
-        kx2[r] = bx2[e];
-        ky2[r] = by2[e];
-        kcls[r] = bcls[e];
+        if (kept_in_lds) {
+          kx1[r] = bx1[e];
+          ky1[r] = by1[e];
+          kx2[r] = bx2[e];
+          ky2[r] = by2[e];
+          kcls[r] = bcls[e];
+        }
         const size_t o = (size_t)b * rows + r;
         ids[o] = bcls[e];
         scores[o] = vy_bits_to_f32((uint32_t)(key[t] >> 32));
@@ -821,6 +836,7 @@ __global__ __launch_bounds__(kAllThreads) void nms_all_kernel(const DetArgs d, v
     }
     // next chunk: everything strictly below this chunk's smallest key
     const unsigned long long last = key[k - 1];
+    if (!kept_in_lds) __threadfence_block();  // the rows just written are the next chunk's kept list
     __syncthreads();
     if (t == 0) n_kept = (nk + add < rows) ? nk + add : rows;
     __syncthreads();
@@ -889,10 +905,11 @@ size_t vy_det_scratch_bytes(int B, int n_items, int C) {
 hipError_t vy_launch_detect(const DetArgs& a, void* scratch, float* ids, float* scores, float* bboxes,
                             int32_t* keep_idx, hipStream_t s) {
   if (a.n_cand >= (1 << kIdxBits)) return hipErrorInvalidValue;
-  // nms_topk <= 0 or > VY_NMS_MAX_TOPK: the chunked kernel, whose kept-row arrays hold post_nms <= VY_NMS_MAX_TOPK rows
+  // nms_topk <= 0 or > VY_NMS_MAX_TOPK: the chunked kernel (kept rows in LDS for outputs of <= VY_NMS_MAX_TOPK rows,
+  // read back from the output itself for longer ones)
   const bool chunked = a.topk <= 0 || a.topk > VY_NMS_MAX_TOPK;
-  if (chunked && (a.post_nms <= 0 || a.post_nms > VY_NMS_MAX_TOPK)) return hipErrorInvalidValue;
-  const int rows = a.post_nms > 0 ? a.post_nms : a.topk;
+  // rows of the output: post_nms, else nms_topk (no slice, yolo3.py:1201-1202), else — both "disabled" — all N*C rows
+  const int rows = a.post_nms > 0 ? a.post_nms : (a.topk > 0 ? a.topk : a.n_cand);
   // state + histogram region back to zero (entries need no clearing)
   hipError_t e = hipMemsetAsync(scratch, 0,
                                 align256(sizeof(SelState) * (size_t)a.B) +

@@ -495,10 +495,6 @@ struct vy_net {
               Hook&& hook) {
     if (int rc = check_ready()) return rc;
     const bool nms_on = nms_thresh > 0.f && nms_thresh < 1.f;  // yolo3.py:1197
-    if (nms_on && (nms_topk <= 0 || nms_topk > VY_MAX_TOPK) && (post_nms <= 0 || post_nms > VY_MAX_TOPK))
-      return fail(VY_ERR_UNSUPPORTED, "nms_topk = %d (<= 0: every valid candidate; > %d: consumed in chunks) needs post_nms "
-                  "in [1, %d] (got %d): the kept rows live in one workgroup's LDS, and the un-sliced output of an "
-                  "unbounded NMS has N*C rows", nms_topk, VY_MAX_TOPK, VY_MAX_TOPK, post_nms);
     FoldDesc* fd = reinterpret_cast<FoldDesc*>(dev_ws + fold_desc_off);
     if (!fold_uploaded) {
       HIP_TRY(hipMemcpyAsync(fd, folds.data(), sizeof(FoldDesc) * folds.size(), hipMemcpyHostToDevice, s));

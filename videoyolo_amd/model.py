@@ -562,10 +562,8 @@ class YOLOV3(object):
         the reference returns the whole (B, N*C, 6) detection tensor (yolo3.py:1197-1202)."""
         if 0 < self.nms_thresh < 1:
             rows = self.post_nms if self.post_nms > 0 else self.nms_topk
-            if rows <= 0:
-                raise _lib.VyError(-4, "nms_topk <= 0 (every valid candidate) needs post_nms >= 1: the un-sliced "
-                                       "output of an unbounded NMS has N*C rows")
-            return rows
+            if rows > 0:
+                return rows  # both "disabled": box_nms's un-sliced output, all N*C rows (yolo3.py:1198-1202)
         return int(self._lib.vy_net_num_anchors(self._h)) * len(self._classes)
 
     def _as_input(self, x):
