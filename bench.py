@@ -227,7 +227,9 @@ def train_leg(vy, dev, dist, rank, world, size, batch, classes, steps, warmup, s
     import torch
     from videoyolo_amd import autograd, targets
     cls_names = ["c%d" % i for i in range(classes)]
-    kw = dict(norm_layer=vy.SyncBatchNorm, norm_kwargs={"num_devices": world}) if (syncbn and world > 1) else {}
+    from videoyolo_amd import parallel
+    multi = world > 1 or parallel.collectives_active()  # (one rank with VY_FORCE_COLLECTIVES=1: the same code path)
+    kw = dict(norm_layer=vy.SyncBatchNorm, norm_kwargs={"num_devices": world}) if (syncbn and multi) else {}
     net = vy.yolo3_darknet53(cls_names, pretrained_base=False, **kw)
     net.initialize(init="synthetic", seed=233)
     net.collect_params().reset_ctx(dev)
@@ -237,7 +239,7 @@ def train_leg(vy, dev, dist, rank, world, size, batch, classes, steps, warmup, s
     tg = targets.YOLOV3PrefetchTargetGenerator(classes)(size, size, gt_boxes, gt_ids)
     dv = [torch.as_tensor(t).to(dev) for t in (gt_boxes,) + tuple(tg)]
     trainer = vy.Trainer(net.collect_params(), 'sgd', {'learning_rate': 1e-3, 'wd': 5e-4, 'momentum': 0.9})
-    if world > 1 and overlap:
+    if multi and overlap:
         trainer.enable_overlap()
     global_batch = batch * world
 
@@ -261,7 +263,8 @@ def train_leg(vy, dev, dist, rank, world, size, batch, classes, steps, warmup, s
     out = {"frames_per_s": fps, "ms_per_step": 1e3 * dt / steps, "n_gpus": world, "per_gpu_batch": batch,
            "global_batch": global_batch, "size": size, "classes": classes, "steps": steps, "warmup": warmup,
            "batchnorm": "SyncBatchNorm(num_devices=%d) on the 6 layers that receive norm_layer" % world if kw else "per-device",
-           "allreduce": ("bucketed, overlapped with backward" if overlap else "one all-reduce after backward") if world > 1 else "none (1 rank)",
+           "allreduce": ("bucketed, overlapped with backward" if overlap else "one all-reduce after backward") if multi else "none (1 rank)",
+           "backend": dist.get_backend() if dist is not None else None,
            "loss_rank0": float(sum(l.sum() for l in losses).item() / batch)}
     if fwd_gflop:
         # whole timed step (forward + backward + exposed all-reduce + SGD) against the roof, per GPU
@@ -290,7 +293,7 @@ def train_leg(vy, dev, dist, rank, world, size, batch, classes, steps, warmup, s
             fl = fwd_gflop * 1e9 * batch
             out.update(forward_tflops=fl / (fw * 1e-3) / 1e12, backward_tflops=2 * fl / (bw * 1e-3) / 1e12,
                        frac_forward_backward=3 * fl / ((fw + bw) * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS)
-    if allreduce_alone and world > 1:
+    if allreduce_alone and multi:
         # the flat gradient buffer (246.5 MB) all-reduced with nothing else on the GPU
         nbytes = net._grads.numel() * 4
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -307,6 +310,8 @@ def train_leg(vy, dev, dist, rank, world, size, batch, classes, steps, warmup, s
         out["allreduce_alone_ms"] = alone
         out["allreduce_bytes"] = nbytes
         out["allreduce_busbw_GBps"] = 2.0 * (world - 1) / world * nbytes / (alone * 1e-3) / 1e9
+        if world == 1:
+            out["allreduce_note"] = "one rank (VY_FORCE_COLLECTIVES): the collective runs through the backend but moves nothing between devices"
         if split:
             out["allreduce_overlap_fraction"] = max(0.0, min(1.0, 1.0 - out["allreduce_exposed_ms"] / alone))
     del trainer, net
@@ -383,6 +388,10 @@ def main():
     ap.add_argument("--syncbn", action="store_true", help="train: SyncBatchNorm statistics all-reduce (configs[4])")
     ap.add_argument("--no-overlap", action="store_true", help="train: all-reduce after backward instead of bucketed")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL over xGMI)")
+    ap.add_argument("--force-collectives", action="store_true",
+                    help="N = 1: initialise the process group anyway and send every broadcast / all-reduce / SyncBatchNorm "
+                         "exchange of the training legs through the backend (VY_FORCE_COLLECTIVES=1): the RCCL code path on "
+                         "one GPU; also_syncbn608 then runs at N = 1 too")
     ap.add_argument("--share-gpu", action="store_true",
                     help="testing only: all ranks use cuda:0 (with --backend gloo) to exercise the N>1 code path on one GPU")
     ap.add_argument("--no-pmc", action="store_true",
@@ -441,13 +450,18 @@ def main():
     if world != args.gpus:
         sys.exit("bench.py --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     dist = None
-    if world > 1:
+    if args.force_collectives:
+        os.environ["VY_FORCE_COLLECTIVES"] = "1"
+    forced = os.environ.get("VY_FORCE_COLLECTIVES", "0") not in ("", "0")
+    if world > 1 or forced:
         import torch.distributed as dist
+        from videoyolo_amd import parallel
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
         if args.share_gpu:
             local = 0
         kw = {"device_id": torch.device("cuda", local)} if args.backend == "nccl" else {}
-        dist.init_process_group(args.backend, rank=rank, world_size=world, **kw)
+        dist.init_process_group(args.backend, rank=rank, world_size=world, timeout=parallel.group_timeout(), **kw)
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
 
@@ -668,7 +682,7 @@ def main():
             leg["traffic"] = None
             leg["traffic_note"] = train_traffic_note
         result["also_train416"] = leg
-        if world > 1:
+        if world > 1 or forced:
             leg = train_leg(vy, dev, dist, rank, world, args.syncbn_size, args.syncbn_batch, args.classes,
                             args.train_steps, args.warmup, syncbn=True, overlap=True, allreduce_alone=False)
             leg["workload"] = ("BASELINE.json configs[4]: SyncBN training step, %dx%d, per-GPU batch %d, net built with "

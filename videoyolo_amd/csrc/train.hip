@@ -312,10 +312,15 @@ struct TrainCtx {
   float* grad_of(int pidx) const { return t->grads + net->params[pidx].info.offset; }
 };
 
+// SyncBatchNorm statistics are exchanged when there is more than one rank — or when a callback was installed for ONE rank
+// (videoyolo_amd.parallel with VY_FORCE_COLLECTIVES=1: the all-reduce over one rank is the identity; it exists so that the
+// whole exchange path, RCCL included, can be executed on a one-GPU box)
+static bool sync_exchange(const VyTrain* t) { return t->world > 1 || (t->world == 1 && t->ar_cb != nullptr); }
+
 // the sums the normalisation uses: the local ones, or (SyncBN layers, world > 1) their all-reduce
 int combine_sums(const TrainCtx& c, const ConvT& cv, int n_cols, double* count, const double** use) {
   *use = c.sums_local();
-  if (c.t->world > 1 && is_sync_layer(cv)) {
+  if (sync_exchange(c.t) && is_sync_layer(cv)) {
     if (!c.t->ar_cb) return fail(VY_ERR_STATE, "SyncBN world > 1 without an all-reduce callback");
     HIP_TRY(hipMemcpyAsync(c.sums_global(), c.sums_local(), sizeof(double) * n_cols, hipMemcpyDeviceToDevice, c.s));
     if (int rc = c.t->ar_cb(c.t->ar_user, c.sums_global(), n_cols))
@@ -372,7 +377,7 @@ int forward_train(const TrainCtx& c, const float* x) {
     const int C = cv.cout;
     // statistics exchange between ranks only for the SyncBatchNorm layers; everywhere else the ordered
     // reduce of the per-tile sums and the finalize are one launch
-    const bool exchange = c.t->world > 1 && is_sync_layer(cv);
+    const bool exchange = sync_exchange(c.t) && is_sync_layer(cv);
     double count = (double)B * zp.H * zp.W;
     const double* use_sums = nullptr;
     if (exchange) {
@@ -651,7 +656,7 @@ int backward_train(const TrainCtx& c, const float* x) {
       bb.ups = cv.ups;
       bb.chunk = vy_bn_bwd_rows_per_chunk(B, zp.H, cv.cout);
       HIP_TRY(vy_launch_bn_bwd_reduce(bb, c.s));
-      const bool exchange = c.t->world > 1 && is_sync_layer(cv);
+      const bool exchange = sync_exchange(c.t) && is_sync_layer(cv);
       double count = (double)B * zp.H * zp.W;
       const double* use_sums = nullptr;
       if (exchange) {

@@ -648,7 +648,7 @@ class YOLOV3(object):
             self._sync_bn_checked = False
             raise ValueError("norm_layer=SyncBatchNorm with num_devices=%s, but the process group has %d rank(s): one "
                              "process drives one GPU (start N ranks: torchrun / videoyolo_amd.launch)" % (nd, world))
-        if world == 1:
+        if world == 1 and not parallel.collectives_active():
             warnings.warn("norm_layer=SyncBatchNorm on a single device: identical to BatchNorm, no statistics exchange")
             return
         if self._sync_hook is None:

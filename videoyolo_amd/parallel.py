@@ -31,6 +31,52 @@ def rank():
     return _dist().get_rank() if is_initialized() else 0
 
 
+def collectives_active():
+    """True when the collectives of this module really run: a process group of more than one rank — or of ONE rank with
+    VY_FORCE_COLLECTIVES=1, which sends every broadcast / all-reduce / SyncBatchNorm exchange of the training path through
+    the backend anyway (an all-reduce over one rank is the identity).  That is how the RCCL code path — the float64
+    [2][C] all-reduce from a ctypes callback, async bucket all-reduces on a side stream, the gloo side group beside an
+    NCCL default group, ``device_id=`` initialisation — is executed on a one-GPU box (tests/test_gpu_rccl.py)."""
+    if not is_initialized():
+        return False
+    return world_size() > 1 or os.environ.get("VY_FORCE_COLLECTIVES", "0") not in ("", "0")
+
+
+_failed = None
+
+
+def fail_group(exc):
+    """A collective raised inside a library callback (or anywhere a peer would otherwise be left waiting): print the
+    traceback, remember the failure and ABORT the process group's communicators, so that this rank's pending and later
+    collectives error out at once instead of queueing behind a dead exchange.  The peers notice through the backend's
+    own error handling (RCCL's watchdog sees the aborted communicator; gloo sees the closed sockets) or, at the latest,
+    through the group timeout (``init_process_group``: VY_DIST_TIMEOUT_S, default 600 s — never the 30-minute library
+    default) — and both launchers (videoyolo_amd.launch, torchrun) terminate the other ranks once this one exits
+    non-zero, which it does because the library call that invoked the callback now returns an error."""
+    global _failed
+    import traceback
+    traceback.print_exception(type(exc), exc, exc.__traceback__)
+    if _failed is None:
+        _failed = exc
+        try:
+            from torch.distributed import distributed_c10d as c10d
+            if hasattr(c10d, "_abort_process_group"):
+                c10d._abort_process_group()
+        except Exception as e:  # pragma: no cover - best effort; the error return below still ends the step
+            print("videoyolo_amd.parallel: abort of the process group failed: %s" % e)
+    return 1
+
+
+def failed():
+    """The exception that made this rank abort its process group, or None."""
+    return _failed
+
+
+def group_timeout():
+    import datetime
+    return datetime.timedelta(seconds=float(os.environ.get("VY_DIST_TIMEOUT_S", "600")))
+
+
 def init_process_group(backend=None):
     """Initialise from the torchrun environment (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_*)."""
     import torch
@@ -47,7 +93,7 @@ def init_process_group(backend=None):
         local = int(os.environ.get("LOCAL_RANK", "0"))
         torch.cuda.set_device(local)
         kw["device_id"] = torch.device("cuda", local)
-    dist.init_process_group(backend, rank=r, world_size=w, **kw)
+    dist.init_process_group(backend, rank=r, world_size=w, timeout=group_timeout(), **kw)
 
 
 def split_sizes(n, parts):
@@ -67,14 +113,14 @@ def scatter_frames(batch, r=None, w=None):
 
 def allreduce_(tensor):
     """In-place sum over all ranks (no-op without a process group)."""
-    if is_initialized() and world_size() > 1:
+    if collectives_active():
         _dist().all_reduce(tensor)
     return tensor
 
 
 def broadcast_(tensor, src=0):
     """In-place broadcast from rank `src` (no-op without a process group)."""
-    if is_initialized() and world_size() > 1:
+    if collectives_active():
         _dist().broadcast(tensor, src=src)
     return tensor
 
@@ -92,7 +138,7 @@ def host_group():
 def make_host_group():
     """Collective: every rank must call it (idempotent)."""
     global _host_group
-    if not is_initialized() or world_size() == 1 or _host_group is not None:
+    if not collectives_active() or _host_group is not None:
         return _host_group
     dist = _dist()
     if dist.get_backend() == "gloo":
@@ -102,11 +148,24 @@ def make_host_group():
             # single node (the launch contract): gloo over loopback — the container's hostname may not resolve
             if os.environ.get("MASTER_ADDR", "127.0.0.1") in ("127.0.0.1", "localhost"):
                 os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
-            _host_group = dist.new_group(backend="gloo")
-        except Exception as e:  # no usable host interface for gloo: every rank of the node fails alike
+            grp = dist.new_group(backend="gloo", timeout=group_timeout())
+        except Exception as e:  # no usable host interface for gloo on THIS rank
             import warnings
-            warnings.warn("no gloo side group (%s): control-plane agreement falls back to one-element RCCL all-reduces "
-                          "with a host read-back per recorded forward" % e)
+            warnings.warn("no gloo side group on rank %d (%s)" % (rank(), e))
+            grp = None
+        # Agree on the outcome: a rank-local failure (interface, environment, fd limit) would otherwise leave some ranks
+        # all-reducing on gloo and the others on RCCL at the first recorded forward — a hang.  One all-reduce(MIN) of
+        # "I have the group" on the DEFAULT group; if any rank failed, every rank uses the fallback.
+        import torch
+        ok = torch.tensor([1 if grp is not None else 0], dtype=torch.int32,
+                          device=torch.device("cuda", torch.cuda.current_device()))
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 1:
+            _host_group = grp
+        else:
+            import warnings
+            warnings.warn("gloo side group unavailable on at least one rank: control-plane agreement falls back to "
+                          "one-element RCCL all-reduces with a host read-back per recorded forward")
             _host_group = False
     return _host_group
 
@@ -115,7 +174,7 @@ def any_rank(flag, device=None):
     """True on every rank iff `flag` is true on at least one: all-reduce(MAX) of one integer.  Every rank must
     call it.  Runs on the host group when there is one (no GPU synchronisation); otherwise on a device tensor of
     the default group (one small RCCL all-reduce and a host read-back)."""
-    if not is_initialized() or world_size() == 1:
+    if not collectives_active():
         return bool(flag)
     import torch
     dist = _dist()
@@ -138,11 +197,13 @@ def sync_replicas(net, src=0):
     rank must reach it: ``Trainer.__init__`` calls it unconditionally; the recorded forward calls
     ``sync_replicas_if_any_dirty`` (below), which first AGREES across ranks on whether anybody wrote parameters."""
     import torch
-    if not is_initialized() or world_size() == 1 or net._dev_params is None:
+    if not collectives_active() or net._dev_params is None:
         return False
     broadcast_(net._dev_params.view(torch.float32), src)
     net._replicas_synced = True
-    net._params_written()  # the device buffer was written behind the library's back
+    written = getattr(net, "_params_written", None)
+    if written is not None:
+        written()  # the device buffer was written behind the library's back (conv mode 'split_bf16x3' caches weight images)
     return True
 
 
@@ -152,7 +213,7 @@ def sync_replicas_if_any_dirty(net, src=0):
     where one process owns all devices).  The decision is an all-reduce(MAX) of the per-rank dirty flags, so all
     ranks take the same branch: a rank-local flag alone would send only the writing ranks into the broadcast and
     hang the others in their next collective."""
-    if not is_initialized() or world_size() == 1 or net._dev_params is None:
+    if not collectives_active() or net._dev_params is None:
         return False
     make_host_group()  # first call on every rank = their first recorded forward (or Trainer()): collective, then cached
     if any_rank(not net._replicas_synced, net._device):
@@ -202,10 +263,8 @@ class SyncBatchNormHook(object):
                 _dist().all_reduce(view)
                 self.calls.append(int(count))
                 return 0
-            except Exception:  # pragma: no cover - surfaced as a library error
-                import traceback
-                traceback.print_exc()
-                return 1
+            except Exception as e:  # surfaced as a library error on this rank; the group is aborted for the peers
+                return fail_group(e)
         self._cb = _lib.ALLREDUCE_CB(cb)
         net._cb_keep.append(self._cb)
         net._sync_hook = self
@@ -232,7 +291,7 @@ class GradBucketOverlap(object):
 
         def cb(user, off, count):
             try:
-                if not is_initialized() or world_size() == 1:
+                if not collectives_active():
                     return 0
                 self.launched.append((int(off), int(count)))
                 ev = torch.cuda.Event()
@@ -242,10 +301,8 @@ class GradBucketOverlap(object):
                     work = _dist().all_reduce(net._grads[off:off + count], async_op=True)
                 self.pending.append(work)
                 return 0
-            except Exception:  # pragma: no cover
-                import traceback
-                traceback.print_exc()
-                return 1
+            except Exception as e:
+                return fail_group(e)
         self._cb = _lib.GRAD_BUCKET_CB(cb)
         net._cb_keep.append(self._cb)
         _lib.check(net._lib.vy_net_set_grad_bucket_cb(net._h, self._cb, None))
