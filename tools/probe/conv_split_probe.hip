@@ -104,6 +104,10 @@ int main(int argc, char** argv) {
     a.sk_partials = (float*)((char*)skp + (size_t)VY_SK_FLAGS * 4);
     a.sk_bytes = VY_SK_PARTIAL_BYTES;
     a.sk_nflags = VY_SK_FLAGS;
+    void* slabs;
+    CK(hipMalloc(&slabs, (size_t)VY_SK_PARTIAL_BYTES));
+    a.splitk_slabs = (float*)slabs;
+    a.splitk_bytes = VY_SK_PARTIAL_BYTES;
   }
   ConvArgs a2 = a;
   a2.out = out2;
@@ -126,6 +130,9 @@ int main(int argc, char** argv) {
     CK(hipEventSynchronize(e1));
     CK(hipEventElapsedTime(&ms_s, e0, e1));
     const double us_e = ms_e * 1e3 / reps, us_s = ms_s * 1e3 / reps;
+    int sbm, sbn, sks;
+    vy_conv_split_cfg(a2, &sbm, &sbn, &sks);
+    printf("[%dx%d k%d] ", sbm, sbn, sks);
     printf("conv B=%d H=%d Cin=%d Cout=%d k=%d s=%d res=%d | M=%d N=%d K=%.0f | exact %.1f us %.1f TF | split %.1f us %.1f TF-eq (%.0f TF bf16) | x%.2f\n",
            B, H, Cin, Cout, k, stride, res, a.M, a.N, K, us_e, gflop / us_e * 1e3, us_s, gflop / us_s * 1e3,
            6 * gflop / us_s * 1e3, us_e / us_s);

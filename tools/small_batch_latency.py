@@ -13,11 +13,16 @@ import videoyolo_amd as vy  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--size", type=int, default=608)
 ap.add_argument("--batches", default="1,2,4,8,16")
+ap.add_argument("--conv-mode", default="exact", choices=["exact", "split_bf16x3"])
+ap.add_argument("--graph", action="store_true", help="hybridize: replay a captured HIP graph")
 a = ap.parse_args()
 net = vy.yolo3_darknet53(["c%d" % i for i in range(20)], pretrained_base=False)
 net.initialize(init="synthetic", seed=233)
 net.collect_params().reset_ctx("cuda:0")
 net.set_nms(0.45, 400, 100)
+net.set_conv_mode(a.conv_mode)
+if a.graph:
+    net.hybridize()
 GF = {608: 139.76, 416: 65.43}.get(a.size)  # forward GFLOP per frame
 for b in [int(t) for t in a.batches.split(",")]:
     x = torch.randn((b, 3, a.size, a.size), device="cuda:0")
@@ -30,6 +35,9 @@ for b in [int(t) for t in a.batches.split(",")]:
         net(x)
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / n * 1e3
-    sk = sum(1 for name, _, _, _ in net.profile(x) if name.endswith("sk"))
-    print("batch %2d: %7.3f ms  %7.1f frames/s  %5.1f TFLOP/s  (%d stream-K launches)"
-          % (b, ms, b / ms * 1e3, (GF * b / ms) if GF else 0.0, sk))
+    names = [name for name, _, _, _ in net.profile(x)]
+    sk = sum(1 for n_ in names if n_.endswith("sk"))
+    sp = sum(1 for n_ in names if "|split" in n_)
+    spk = sum(1 for n_ in names if "|split" in n_ and "k" in n_.split("|split")[1])
+    print("batch %2d: %7.3f ms  %7.1f frames/s  %5.1f TFLOP/s  (%d stream-K launches, %d split-fp32 launches of which %d k-split)"
+          % (b, ms, b / ms * 1e3, (GF * b / ms) if GF else 0.0, sk, sp, spk))

@@ -96,19 +96,31 @@ struct VySplitModel {
 };
 static const VySplitModel kVySplitModels[3] = {{128, 128, 0.0372, 3.0, 1.10}, {128, 64, 0.0227, 2.0, 1.40}, {256, 64, 0.043, 4.5, 1.10}};
 
-// predicted time (microseconds) of the launch on the split-fp32 kernel and the tile it would use; N % 64 == 0
-inline double vy_predict_split(long long M, int N, double K, int* bm, int* bn) {
+// predicted time (microseconds) of the launch on the split-fp32 kernel, the tile and the k-split it would use; N % 64 == 0.
+// k-split S > 1 (at most max_ksplit: what the slab scratch holds): tiles x S blocks of K / S each plus the finish
+// launch — for launches that leave most CUs without a block (a single frame's 19x19 layer: 24 tiles of 288 k-steps).
+// Fitted on tools/probe/run_split_ksplit_sweep.sh: the second launch, the slab round trip and the short k-loops'
+// pipeline fill cost about 8 us (19x19, K = 4608, one frame: 190 us unsplit, 36.7 us as 8 slices; the exact kernel 75 us).
+inline double vy_predict_split(long long M, int N, double K, int max_ksplit, int* bm, int* bn, int* ksplit) {
   double best = 1e300;
+  *ksplit = 1;
   for (const VySplitModel& c : kVySplitModels) {
     if (N % c.bn != 0) continue;
     if (c.bm == 256 && N % 128 == 0) continue;  // the 256-row tile is the 64-channel layers' only
     const long long tiles = ((M + c.bm - 1) / c.bm) * (N / c.bn);
-    double t = (double)((tiles + 255) / 256) * (c.alpha * K + c.fixed);
-    if (tiles <= 256) t *= c.lone;
-    if (t < best * 0.995) {
-      best = t;
-      *bm = c.bm;
-      *bn = c.bn;
+    const int steps = (int)(K / 16.0);
+    for (int S = 1; S <= max_ksplit && S <= 32; ++S) {
+      if (S > 1 && (tiles * (S - 1) >= 512 || steps / S < 6)) break;  // only while CUs have room and slices stay long enough
+      const long long blocks = tiles * S;
+      double t = (double)((blocks + 255) / 256) * (c.alpha * K / S + c.fixed);
+      if (blocks <= 256) t *= c.lone;
+      if (S > 1) t += 8.0;
+      if (t < best * 0.995) {
+        best = t;
+        *bm = c.bm;
+        *bn = c.bn;
+        *ksplit = S;
+      }
     }
   }
   return best;

@@ -116,7 +116,11 @@ hipError_t vy_launch_split_weights(const float* w, void* img, int cout, int taps
 // NSA = LDS stages of the A tile (written one k-step ahead: two suffice; three where they fit let the loop unroll by 3
 // instead of 6); the W tile always has three (its DMA is issued two k-steps ahead).
 template <int BM, int BN, int NSA>
-__global__ __launch_bounds__(256, 2) void conv_split_kernel(const ConvArgs a, const int tiles_n) {
+// ksplit > 1: split-K for launches of few tiles (a single frame's deep layers): block (tile, s) runs k-steps
+// [s T / ksplit, (s + 1) T / ksplit) and stores its raw accumulators to slab s of a.splitk_slabs ([ksplit][M][N] fp32);
+// splitk_finish_kernel adds the slabs in order and applies the epilogue.  (The exact kernel cannot do this — its fma
+// chain is pinned — which is why a single 608x608 frame is bound by the chain of ONE wave per SIMD there.)
+__global__ __launch_bounds__(256, 2) void conv_split_kernel(const ConvArgs a, const int tiles_n, const int ksplit) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int WM = 2, WN = 2, NW = 4, NT = 256;
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
@@ -147,7 +151,9 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(const ConvArgs a, co
   const int wm = wave / WN, wn = wave % WN;
   const int h = lane >> 5, lrow = lane & 31;
   const int cch = a.Kc >> 4;  // 16-channel chunks per tap
-  const int tile_m = vblk / tiles_n, tile_n = vblk - tile_m * tiles_n;
+  const int n_tiles = (int)(gridDim.x / (unsigned)ksplit);
+  const int ks_idx = vblk / n_tiles, vtile = vblk - ks_idx * n_tiles;  // k-slice major: one slice's tiles are neighbours in time
+  const int tile_m = vtile / tiles_n, tile_n = vtile - tile_m * tiles_n;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
   long long pix0;
@@ -209,10 +215,12 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(const ConvArgs a, co
       for (int r = 0; r < NR; ++r) acc[i][j][r] = 0.0f;
 
   const unsigned lds0 = (unsigned)(unsigned long long)LDS_PTR(smem);
-  const int T = a.ntaps * cch;
+  const int T_all = a.ntaps * cch;
+  const int kb = (int)((long long)ks_idx * T_all / ksplit), ke = (int)((long long)(ks_idx + 1) * T_all / ksplit);
+  const int T = ke - kb;  // k-steps of this block (>= 1: the launcher keeps ksplit <= T_all)
 
   // wave-uniform k-step state
-  int n_tap = 0, n_cc = 0;
+  int n_tap = kb / cch, n_cc = kb - (kb / cch) * cch;
   int a_koff = 0;
   long long w_koff = 0;
   auto advance = [&]() {
@@ -372,6 +380,21 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(const ConvArgs a, co
     else kstep(stw, sta, N_{}, N_{});
   }
 
+  if (ksplit > 1) {  // raw partial sums to this k-slice's slab; the epilogue belongs to splitk_finish_kernel
+    float* slab = a.splitk_slabs + (long long)ks_idx * a.M * a.N;
+#pragma unroll
+    for (int j = 0; j < TNs; ++j) {
+      const int n = n0 + wn * (BN / WN) + j * TS + (M16 ? r16 : lrow);
+#pragma unroll
+      for (int i = 0; i < TMs; ++i)
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+          const int m = m0 + wm * (BM / WM) + i * TS + (M16 ? 4 * q16 + r : (r & 3) + 8 * (r >> 2) + 4 * h);
+          if (m < a.M && n < a.N) slab[(long long)m * a.N + n] = acc[i][j][r];
+        }
+    }
+    return;
+  }
   // ---- epilogue (conv_igemm.hip): affine -> leaky -> + addend -> store (x1 or x2-replicated)
   constexpr int kRsrcFlags = 0x00020000;
   const __amdgpu_buffer_rsrc_t out_rsrc =
@@ -451,20 +474,30 @@ bool vy_conv_split_supported(const ConvArgs& a) {
   return (bn_cell && (a.ups != 2 || !a.res)) || bias;
 }
 
-// block tile of a launch: the cost model's choice (conv_cost_model.h) among 128x128, 128x64 and, for the 64-channel
-// layers, 256x64
-void vy_conv_split_cfg(const ConvArgs& a, int* bm, int* bn) {
-  static const char* force = getenv("VY_SPLIT_FORCE");  // experiments: VY_SPLIT_FORCE=128x64
-  if (force && sscanf(force, "%dx%d", bm, bn) == 2 && a.N % *bn == 0) return;
-  vy_predict_split(a.M, a.N, (double)a.ntaps * a.Kc, bm, bn);
+// block tile and k-split of a launch: the cost model's choice (conv_cost_model.h) among 128x128, 128x64 and, for the
+// 64-channel layers, 256x64; k-split > 1 only where the slabs fit the scratch the net provides
+static long long split_max_ksplit(const ConvArgs& a) {
+  if (!a.splitk_slabs) return 1;
+  return std::max<long long>(1, (long long)(a.splitk_bytes / ((unsigned long long)a.M * a.N * 4ull)));
+}
+
+void vy_conv_split_cfg(const ConvArgs& a, int* bm, int* bn, int* ksplit) {
+  static const char* force = getenv("VY_SPLIT_FORCE");  // experiments: VY_SPLIT_FORCE=128x64 or 128x64x4 (k-split)
+  int fks = 1;
+  if (force && sscanf(force, "%dx%dx%d", bm, bn, &fks) >= 2 && a.N % *bn == 0) {
+    *ksplit = (int)std::min<long long>(std::max(1, fks), split_max_ksplit(a));
+    return;
+  }
+  vy_predict_split(a.M, a.N, (double)a.ntaps * a.Kc, (int)std::min<long long>(split_max_ksplit(a), 64), bm, bn, ksplit);
 }
 
 bool vy_conv_split_pays(const ConvArgs& a) {
   if (!vy_conv_split_supported(a)) return false;
   const char* always = getenv("VY_SPLIT_ALWAYS");  // tests: every supported launch, however small (read per call)
   if (always && atoi(always)) return true;
-  int bm, bn;
-  return vy_predict_split(a.M, a.N, (double)a.ntaps * a.Kc, &bm, &bn) < 0.97 * vy_conv_predict_us(a);
+  int bm, bn, ks;
+  return vy_predict_split(a.M, a.N, (double)a.ntaps * a.Kc, (int)std::min<long long>(split_max_ksplit(a), 64), &bm, &bn, &ks) <
+         0.97 * vy_conv_predict_us(a);
 }
 
 static VyFastDiv split_fastdiv(unsigned d) {
@@ -477,10 +510,61 @@ static VyFastDiv split_fastdiv(unsigned d) {
   return f;
 }
 
+// second launch of a split-K conv: out = epilogue(sum over s of slab s), slabs added in index order (deterministic).
+// One thread = 4 consecutive channels of one output pixel.
+__global__ __launch_bounds__(256) void splitk_finish_kernel(const ConvArgs a, const int ksplit) {
+  const int nq = a.N >> 2;
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long long)a.M * nq) return;
+  const int m = (int)(idx / nq), n = (int)(idx - (long long)m * nq) << 2;
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  const float* p = a.splitk_slabs + (long long)m * a.N + n;
+  for (int s = 0; s < ksplit; ++s) {
+    const f32x4 t = *reinterpret_cast<const f32x4*>(p + (long long)s * a.M * a.N);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] += t[e];
+  }
+  const int t = (int)fd_div((unsigned)m, a.fd_lw);
+  const int x = m - t * a.LW;
+  const int b = (int)fd_div((unsigned)t, a.fd_lh);
+  const int y = t - b * a.LH;
+  const long long pix = (long long)(b * a.o_Hp + y * a.o_s + a.o_oy) * a.o_Wp + x * a.o_s + a.o_ox;
+  const f32x4 sh = *reinterpret_cast<const f32x4*>(a.shift + n);
+  if (a.scale) {
+    const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scale + n);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = fmaf(v[e], sc[e], sh[e]);
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = v[e] + sh[e];
+  }
+  if (a.leaky) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = vy_leaky(v[e]);
+  }
+  if (a.res) {
+    const f32x4 r = *reinterpret_cast<const f32x4*>(a.res + pix * a.r_cs + a.r_co + n);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = v[e] + r[e];
+  }
+  float* o = a.out + pix * a.o_cs + a.o_co + n;
+  *reinterpret_cast<f32x4*>(o) = v;
+  if (a.ups == 2) {  // x2-replicated store cropped to the route's size (conv_igemm.hip, row tables)
+    const bool dx = 2 * x + 1 < a.o_Wp - 2, dy = 2 * y + 1 < a.o_Hp - 2;
+    if (dx) *reinterpret_cast<f32x4*>(o + a.o_cs) = v;
+    if (dy) *reinterpret_cast<f32x4*>(o + (long long)a.o_Wp * a.o_cs) = v;
+    if (dx && dy) *reinterpret_cast<f32x4*>(o + (long long)(a.o_Wp + 1) * a.o_cs) = v;
+  }
+}
+
 template <int BM, int BN, int NSA>
-static hipError_t launch_split(const ConvArgs& a, hipStream_t s) {
+static hipError_t launch_split(const ConvArgs& a, int ksplit, hipStream_t s) {
   const int tiles_m = (a.M + BM - 1) / BM, tiles_n = a.N / BN;
-  hipLaunchKernelGGL((conv_split_kernel<BM, BN, NSA>), dim3(tiles_m * tiles_n), dim3(256), 0, s, a, tiles_n);
+  hipLaunchKernelGGL((conv_split_kernel<BM, BN, NSA>), dim3(tiles_m * tiles_n * ksplit), dim3(256), 0, s, a, tiles_n, ksplit);
+  if (ksplit > 1) {
+    const long long work = (long long)a.M * (a.N >> 2);
+    hipLaunchKernelGGL(splitk_finish_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, s, a, ksplit);
+  }
   return hipGetLastError();
 }
 
@@ -497,10 +581,10 @@ hipError_t vy_launch_conv_split(const ConvArgs& a_in, hipStream_t s) {
     a.pk_dx |= (unsigned)(a.tap_dx[t] + 1) << (2 * t);
     a.pk_w |= (unsigned long long)a.tap_w[t] << (4 * t);
   }
-  int bm, bn;
-  vy_conv_split_cfg(a, &bm, &bn);
-  if (bm == 128 && bn == 128) return launch_split<128, 128, 3>(a, s);
-  if (bm == 256 && bn == 64) return launch_split<256, 64, 2>(a, s);
-  if (bm == 128 && bn == 64) return launch_split<128, 64, 3>(a, s);
+  int bm, bn, ks;
+  vy_conv_split_cfg(a, &bm, &bn, &ks);
+  if (bm == 128 && bn == 128) return launch_split<128, 128, 3>(a, ks, s);
+  if (bm == 256 && bn == 64) return launch_split<256, 64, 2>(a, ks, s);
+  if (bm == 128 && bn == 64) return launch_split<128, 64, 3>(a, ks, s);
   return hipErrorInvalidValue;
 }

@@ -52,6 +52,10 @@ struct ConvArgs {
   int sk_nflags;
   // conv_split.hip only: this conv's weights as pre-split bf16 tile images (vy_launch_split_weights); nullable
   const void* w_split;
+  // ... and scratch for its split-K launches ([ksplit][M][N] fp32 partial sums): the same workspace region as
+  // sk_partials (a stream never runs a stream-K exact launch and a split-K launch at once); nullable: no k-split
+  float* splitk_slabs;
+  unsigned long long splitk_bytes;
 };
 #define VY_SK_PARTIAL_BYTES (32u << 20)  // 512 blocks x 128x128 fp32 (the largest instance: 2 blocks per CU x 256 CUs)
 #define VY_SK_FLAGS 2048
@@ -76,7 +80,7 @@ int vy_sk_verify_topology(unsigned* scratch_dev, hipStream_t s);
 size_t vy_split_weight_bytes(int cout, int taps, int cin);
 hipError_t vy_launch_split_weights(const float* w, void* img, int cout, int taps, int cin, hipStream_t s);
 bool vy_conv_split_supported(const ConvArgs& a);   // forward, N % 64 == 0, Kc % 32 == 0, an epilogue the kernel has
-void vy_conv_split_cfg(const ConvArgs& a, int* bm, int* bn);  // block tile the launch will use
+void vy_conv_split_cfg(const ConvArgs& a, int* bm, int* bn, int* ksplit);  // block tile and k-split the launch will use
 // conv mode VY_CONV_SPLIT_BF16X3, per launch: supported AND predicted faster than the exact kernel (small launches —
 // a single frame's deep layers — stay on the exact kernel, which has the small tiles and stream-K)
 bool vy_conv_split_pays(const ConvArgs& a);

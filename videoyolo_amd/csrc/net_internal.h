@@ -431,6 +431,8 @@ struct vy_net {
     a.leaky = c.leaky;
     a.dgrad = 0;
     a.w_split = c.split_off >= 0 ? dev_ws + wsplit_off + c.split_off : nullptr;
+    a.splitk_slabs = reinterpret_cast<float*>(dev_ws + sk_off + al((size_t)VY_SK_FLAGS * sizeof(unsigned)));
+    a.splitk_bytes = VY_SK_PARTIAL_BYTES;
     set_sk(a);
     return a;
   }
@@ -546,9 +548,10 @@ struct vy_net {
                                  (double)a.N * a.ntaps * a.Kc + (a.res ? (double)a.M * a.N : 0.0));
         char nm[96];
         if (a.w_split && vy_conv_split_pays(a)) {
-          int sbm, sbn;
-          vy_conv_split_cfg(a, &sbm, &sbn);
-          snprintf(nm, sizeof nm, "%s|split%dx%d", c.name.c_str(), sbm, sbn);
+          int sbm, sbn, sks;
+          vy_conv_split_cfg(a, &sbm, &sbn, &sks);
+          if (sks > 1) snprintf(nm, sizeof nm, "%s|split%dx%dk%d", c.name.c_str(), sbm, sbn, sks);
+          else snprintf(nm, sizeof nm, "%s|split%dx%d", c.name.c_str(), sbm, sbn);
           hook(nm, fl, by, true);
           HIP_TRY(vy_launch_conv_split(a, s));
           hook(nm, fl, by, false);
