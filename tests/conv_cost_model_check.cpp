@@ -26,7 +26,20 @@ int main() {
     bool sk = false, sk0 = true;
     const double t = vy_select_tile(s.M, s.N, s.K, on, &bm, &bn, &sk);
     const double t0 = vy_select_tile(s.M, s.N, s.K, off, &bm0, &bn0, &sk0);
-    printf("%lld %d %.0f -> %dx%d%s\n", s.M, s.N, s.K, bm, bn, sk ? "sk" : "");
+    printf("%lld %d %.0f -> %dx%d%s", s.M, s.N, s.K, bm, bn, sk ? "sk" : "");
+    // conv mode VY_CONV_SPLIT_BF16X3 (round 4): which kernel the launch goes to (vy_conv_split_pays: the split model's
+    // time against 0.97 x the exact model's), and the split kernel's tile / k-split
+    if (s.N % 64 == 0) {
+      int sbm = 0, sbn = 0, sks = 0;
+      const double ts = vy_predict_split(s.M, s.N, s.K, 64, &sbm, &sbn, &sks);
+      if (ts < 0.97 * t) printf("   | split %dx%d%s%.0d", sbm, sbn, sks > 1 ? " k" : "", sks > 1 ? sks : 0);
+      else printf("   | exact");
+      if (sks < 1 || (sks > 1 && (s.K / 16) / sks < 6)) return fprintf(stderr, "k-split with slices shorter than 6 k-steps\n"), 1;
+      int b1, b2, k1;
+      if (vy_predict_split(s.M, s.N, s.K, 1, &b1, &b2, &k1) < ts - 1e-9 || k1 != 1)
+        return fprintf(stderr, "allowing k-split made the split prediction worse\n"), 1;
+    }
+    printf("\n");
     if (sk0) return fprintf(stderr, "stream-K chosen although not allowed\n"), 1;
     if (t > t0 * (1.0 + 1e-12)) return fprintf(stderr, "allowing stream-K made the prediction worse\n"), 1;
     if (s.N <= 32 && !(bm == 128 && bn == 32 && !sk)) return fprintf(stderr, "N <= 32 must use the 128x32 tile\n"), 1;

@@ -135,6 +135,42 @@ def test_split_intermediate_cells(voc_classes, synth20, name):
     assert not np.array_equal(got, want)
 
 
+@pytest.mark.parametrize("name,src,k,stride", [("stages.0.1", "stages.0.0", 3, 2), ("stages.1.0", "stages.0.14.body.1", 3, 2),
+                                               ("yolo_blocks.0.tip", "yolo_blocks.0.body.4", 3, 1),
+                                               ("yolo_blocks.0.body.2", "yolo_blocks.0.body.1", 1, 1)])
+def test_kernel_computes_the_six_products(voc_classes, synth20, name, src, k, stride, capsys):
+    """One cell against oracle/split_oracle.py: the cell's actual fp32 input (the tap of the cell before it) is cut into
+    three bf16 planes on the CPU, the SIX partial products are summed in float64, affine + leaky applied — the kernel may
+    differ from that only by the rounding of its fp32 accumulation (bar: 2^-22 of sum |x w| per output, observed far
+    inside).  The same reference with ONE product left out (h_x l_w) must lie well outside what the kernel delivers:
+    the test would notice a missing product.  K = 288, 1024, 2304, 4608; stride 1 and 2; 3x3 and 1x1."""
+    from oracle import split_oracle as S
+    from oracle import yolo3_oracle as O
+    x = frames(2, 64, seed=7)
+    net = _net(voc_classes, synth20)
+    net.keep_activations()
+    net(x)
+    a_in = net.read_activation(src).cpu().numpy()
+    got = net.read_activation(name).cpu().numpy().astype(np.float64)
+    w = synth20[name + ".0.weight"]
+    sc, sh = O.bn_fold(synth20[name + ".1.gamma"], synth20[name + ".1.beta"], synth20[name + ".1.running_mean"],
+                       synth20[name + ".1.running_var"])
+    sc, sh = sc.astype(np.float64).reshape(1, -1, 1, 1), sh.astype(np.float64).reshape(1, -1, 1, 1)
+
+    def finish(z):
+        y = z * sc + sh
+        return np.where(y > 0, y, 0.1 * y)
+    six = finish(S.conv_split_ref(a_in, w, stride, k // 2))
+    five = finish(S.conv_split_ref(a_in, w, stride, k // 2, S.FIVE))
+    bound = S.abs_product_sum(a_in, w, stride, k // 2) * np.abs(sc) * 2.0 ** -22 + 1e-6
+    err6, err5 = np.abs(got - six), np.abs(got - five)
+    with capsys.disabled():
+        print("\n[%s K=%d] max |kernel - six products| %.2e (bound min %.2e) | against five products %.2e" %
+              (name, w.shape[1] * k * k, err6.max(), bound.min(), err5.max()))
+    assert (err6 <= bound).all()
+    assert err5.max() > 4 * err6.max()
+
+
 @pytest.mark.parametrize("batch,size,obj_bias", [(2, 96, 0.0), (2, 128, -3.0), (1, 416, 0.0), (2, 160, -5.0)])
 def test_split_detections_match_oracle(voc_classes, batch, size, obj_bias, capsys):
     from videoyolo_amd import init

@@ -238,11 +238,12 @@ struct WgradArgs {
 hipError_t vy_launch_wgrad(const WgradArgs& a, hipStream_t s);
 // output rows (dz channels) of a weight-gradient block tile: 64 or 128 (the planner's split count depends on it)
 int vy_wgrad_tile_rows(int Cout, int k, int Cin);
-// per-pixel byte offsets (dz vector, input-plane centre pixel shifted by one row + one column) for vy_launch_wgrad;
-// n_entries = vy_wgrad_table_entries(M); both planes must be smaller than 4 GiB
+// per-pixel byte offsets (dz vector, input-plane centre pixel shifted by one row + one column) for vy_launch_wgrad,
+// relative to the first pixel of the pixel's split (k_per_split: the WgradArgs value the table will be used with);
+// n_entries = vy_wgrad_table_entries(M).  Planes may be of any size (round 3: < 4 GiB).
 inline size_t vy_wgrad_table_entries(long long M) { return (size_t)((M + 31) / 32 * 32 + 32); }
 hipError_t vy_launch_wgrad_table(void* tab, int M, int n_entries, int Ho, int Wo, int z_cs, int a_Hp, int a_Wp, int a_cs,
-                                 int stride, hipStream_t s);
+                                 int stride, int B, int k_per_split, hipStream_t s);
 // dst[i] = sum_s slabs[s][i]  (fixed order)
 hipError_t vy_launch_slab_reduce(const float* slabs, int splits, long long n, float* dst, hipStream_t s);
 

@@ -546,12 +546,10 @@ int build_wgrad_tables(const TrainCtx& c) {
     const int Ho = ip.H / cv.stride, Wo = ip.W / cv.stride;
     const long long M = (long long)net->B * Ho * Wo;
     const int z_cs = cv.p_gamma >= 0 ? c.t->z[ci].C : net->planes[cv.out_plane].C;
-    const unsigned long long zbytes = (unsigned long long)net->B * (Ho + 2) * (Wo + 2) * z_cs * 4ull;
-    const unsigned long long abytes = (unsigned long long)net->B * (ip.H + 2) * (ip.W + 2) * ip.C * 4ull;
-    if (zbytes >= (1ull << 32) || abytes >= (1ull << 32))
-      return fail(VY_ERR_UNSUPPORTED, "training plane of '%s' is 4 GiB or larger (32-bit pixel offsets)", cv.name.c_str());
+    if (M >= (1ll << 31) - 64) return fail(VY_ERR_UNSUPPORTED, "'%s': 2^31 output pixels or more in one batch", cv.name.c_str());
+    // (offsets are relative to each split's first pixel: planes of 4 GiB and more are fine — 608x608 past batch 84)
     HIP_TRY(vy_launch_wgrad_table(net->dev_ws + c.t->tab_off[ci], (int)M, (int)vy_wgrad_table_entries(M), Ho, Wo, z_cs,
-                                  ip.H + 2, ip.W + 2, ip.C, cv.stride, c.s));
+                                  ip.H + 2, ip.W + 2, ip.C, cv.stride, net->B, c.t->kps[ci], c.s));
   }
   c.t->tabs_built = true;
   return 0;

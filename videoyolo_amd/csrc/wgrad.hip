@@ -44,24 +44,43 @@ __device__ __forceinline__ void lds_dma16_s(unsigned voff, const float* sbase, u
 // the dz plane (contributes 0 to every sum) and a valid input pixel.  With it the k-loop needs no coordinates at all:
 // the fp32 MFMA shares the vector pipe (tools/probe/coissue_probe.hip), and the incremental per-lane coordinates of
 // round 1 cost 92 vector instructions per 64 MFMAs.
+// (round 4) Entries are 32-bit byte offsets RELATIVE to the first pixel of the entry's split (`k_per_split` pixels of the
+// reduction go to one block; offsets grow with the pixel index, so they are >= 0 and a split spans far less than
+// 4 GiB): the planes themselves may be of any size.  The kernel adds the split's base — wgrad_split_base, the same
+// formulas — to its wave-uniform DMA base once per block.  Dead entries point at the bottom-left border pixel of the LAST
+// image (zero, and behind every valid pixel) and at the last valid input pixel.
+struct WgradPix {
+  unsigned long long zo, ao;
+};
+__device__ __forceinline__ WgradPix wgrad_pixel_offsets(int p, int Ho, int Wo, int z_cs, int a_Hp, int a_Wp, int a_cs, int stride) {
+  const int x = p % Wo, t = p / Wo, y = t % Ho, b = t / Ho;
+  WgradPix o;
+  o.zo = ((unsigned long long)(b * (Ho + 2) + y + 1) * (Wo + 2) + x + 1) * z_cs * 4ull;
+  o.ao = ((unsigned long long)(b * a_Hp + y * stride + 1) * a_Wp + x * stride + 1) * a_cs * 4ull;
+  return o;
+}
+
 __global__ __launch_bounds__(256) void wgrad_table_kernel(uint2* __restrict__ tab, int M, int n_entries, int Ho, int Wo,
-                                                          int z_cs, int a_Hp, int a_Wp, int a_cs, int stride) {
+                                                          int z_cs, int a_Hp, int a_Wp, int a_cs, int stride, int B,
+                                                          int k_per_split) {
   const int p = blockIdx.x * 256 + threadIdx.x;
   if (p >= n_entries) return;
-  const int pp = p < M ? p : 0;
-  const int x = pp % Wo, t = pp / Wo, y = t % Ho, b = t / Ho;
-  const unsigned long long zo = ((unsigned long long)(b * (Ho + 2) + y + 1) * (Wo + 2) + x + 1) * z_cs * 4ull;
-  const unsigned long long ao = ((unsigned long long)(b * a_Hp + y * stride + 1) * a_Wp + x * stride + 1) * a_cs * 4ull;
+  const int pp = p < M ? p : M - 1;
+  const int split = pp / k_per_split;
+  const WgradPix base = wgrad_pixel_offsets(split * k_per_split, Ho, Wo, z_cs, a_Hp, a_Wp, a_cs, stride);
+  const WgradPix o = wgrad_pixel_offsets(pp, Ho, Wo, z_cs, a_Hp, a_Wp, a_cs, stride);
+  const unsigned long long dead = ((unsigned long long)((B - 1) * (Ho + 2) + Ho + 1) * (Wo + 2)) * z_cs * 4ull;
   uint2 e;
-  e.x = p < M ? (unsigned)zo : 0u;  // dead pixel: plane pixel (0, 0) of image 0 — a zero border pixel
-  e.y = (unsigned)ao;
+  e.x = (unsigned)((p < M ? o.zo : dead) - base.zo);
+  e.y = (unsigned)(o.ao - base.ao);
   tab[p] = e;
 }
 
 hipError_t vy_launch_wgrad_table(void* tab, int M, int n_entries, int Ho, int Wo, int z_cs, int a_Hp, int a_Wp, int a_cs,
-                                 int stride, hipStream_t s) {
+                                 int stride, int B, int k_per_split, hipStream_t s) {
+  if (k_per_split < 1 || B < 1) return hipErrorInvalidValue;
   hipLaunchKernelGGL(wgrad_table_kernel, dim3((n_entries + 255) / 256), dim3(256), 0, s, static_cast<uint2*>(tab), M,
-                     n_entries, Ho, Wo, z_cs, a_Hp, a_Wp, a_cs, stride);
+                     n_entries, Ho, Wo, z_cs, a_Hp, a_Wp, a_cs, stride, B, k_per_split);
   return hipGetLastError();
 }
 
@@ -135,8 +154,15 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a, const 
   // past Cout / past k*k*Cin read whatever follows in memory: those rows / columns of the tile are never stored,
   // and an MFMA output element depends on its own row and column only.
   const uint2* tab = a.tab + p_begin;                                      // wave-uniform
-  const float* z_base = a.dz;
-  const float* a_base = a.a + a.a_co - (long long)(a.a_Wp + 1) * a.a_cs;  // tap offsets become >= 0
+  // the split's first pixel: the table's offsets are relative to it (wave-uniform; 32-bit divisions + readfirstlane,
+  // sk-kernel lesson: a 64-bit division is expanded into vector code whose results stop counting as uniform)
+  const WgradPix sb = wgrad_pixel_offsets(p_begin, a.Ho, a.Wo, a.z_cs, a.a_Hp, a.a_Wp, a.a_cs, a.stride);
+  auto uni64 = [](unsigned long long v) {
+    return ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) |
+           (unsigned)__builtin_amdgcn_readfirstlane((int)v);
+  };
+  const float* z_base = a.dz + (uni64(sb.zo) >> 2);
+  const float* a_base = a.a + (uni64(sb.ao) >> 2) + a.a_co - (long long)(a.a_Wp + 1) * a.a_cs;  // tap offsets become >= 0
   const unsigned zc = (unsigned)ao * 4u;
   const unsigned ac = (unsigned)((((dy + 1) * a.a_Wp + (dx + 1)) * a.a_cs + cin) * 4);
   const int zrow0 = A_RPI * wave + a_sub, arow0 = 2 * wave + h;  // + 4 * A_RPI * j / + 8 * j
