@@ -21,6 +21,8 @@ Prints ONE JSON line on rank 0 (contract in the task statement) with extra objec
                   products, fp32 accumulate — NOT the parity path; tolerances in tests/test_gpu_split.py): frames/s,
                   conv rate against the fp32 roof and against the bf16 roof / 6, batch-1 latency, HBM traffic.
                   The headline `value` stays the exact-fp32 path.
+  also_train416_split  (--train-split-leg only) BASELINE configs[2] with the recorded forward and the data gradients in
+                  conv mode split_bf16x3_train (weight gradients exact)
   also_train416   BASELINE configs[2] at the same N: training step 416x416, 16 frames per GPU (recorded forward +
                   backward + gradient all-reduce over RCCL, bucketed and overlapped + SGD), timed the same way
                   (barrier + synchronize, max over ranks) — with the forward / backward / exposed-all-reduce split,
@@ -217,7 +219,7 @@ def _max_over_ranks(dt, dist, torch, dev):
 
 
 def train_leg(vy, dev, dist, rank, world, size, batch, classes, steps, warmup, syncbn=False, overlap=True,
-              split=True, allreduce_alone=False):
+              split=True, allreduce_alone=False, conv_mode="exact"):
     """One training workload, timed like the headline: `warmup` un-timed steps, then exactly `steps` steps between
     barrier + synchronize, max over ranks.  One step = recorded forward (batch-statistics BatchNorm, targets, loss)
     + backward + gradient all-reduce (bucketed, overlapped with backward) + SGD: the call pattern of
@@ -233,6 +235,7 @@ def train_leg(vy, dev, dist, rank, world, size, batch, classes, steps, warmup, s
     net = vy.yolo3_darknet53(cls_names, pretrained_base=False, **kw)
     net.initialize(init="synthetic", seed=233)
     net.collect_params().reset_ctx(dev)
+    net.set_conv_mode(conv_mode)  # 'split_bf16x3': recorded forward + data gradients on the split kernel (weight gradients exact)
     g = torch.Generator(device="cpu").manual_seed(1233 + rank)
     x = torch.randn((batch, 3, size, size), generator=g, dtype=torch.float32).to(dev)
     gt_boxes, gt_ids = targets.synthetic_gt(batch, size, classes, m=8, seed=100 + rank)
@@ -397,10 +400,13 @@ def main():
     ap.add_argument("--no-pmc", action="store_true",
                     help="skip the rocprofv3 --pmc child runs that measure roofline.traffic (N = 1 only)")
     ap.add_argument("--no-latency", action="store_true", help="skip the batch-1 latency figure (N = 1 inference only)")
-    ap.add_argument("--conv-mode", choices=["exact", "split_bf16x3"], default="exact",
+    ap.add_argument("--conv-mode", choices=["exact", "split_bf16x3", "split_bf16x3_train"], default="exact",
                     help="arithmetic of the HEADLINE inference step (default exact fp32: the parity path); the default "
                          "line reports the split mode beside it as also_infer608_split")
     ap.add_argument("--no-split-leg", action="store_true", help="skip also_infer608_split")
+    ap.add_argument("--train-split-leg", action="store_true",
+                    help="add also_train416_split: the training step in conv mode split_bf16x3_train (experimental: measured "
+                         "no faster than the exact step, which is bound by the weight gradients)")
     ap.add_argument("--no-train-legs", action="store_true",
                     help="infer mode: skip also_train416 / also_syncbn608 (BASELINE configs[2] / [4])")
     ap.add_argument("--train-steps", type=int, default=10, help="timed steps of each training leg")
@@ -682,6 +688,15 @@ def main():
             leg["traffic"] = None
             leg["traffic_note"] = train_traffic_note
         result["also_train416"] = leg
+        if args.train_split_leg:
+            # the same training step with forward + data gradients in the split-fp32 conv mode (experimental; slower)
+            sleg = train_leg(vy, dev, dist, rank, world, args.train_size, args.train_batch, args.classes,
+                             args.train_steps, args.warmup, syncbn=False, overlap=True, allreduce_alone=False,
+                             conv_mode="split_bf16x3_train")
+            sleg["dtype"] = SPLIT_DTYPE + " (recorded forward and data gradients; weight gradients exact f32)"
+            sleg["speedup_over_exact"] = sleg["frames_per_s"] / leg["frames_per_s"]
+            sleg["workload"] = leg["workload"] + "; net.set_conv_mode('split_bf16x3')"
+            result["also_train%d_split" % args.train_size] = sleg
         if world > 1 or forced:
             leg = train_leg(vy, dev, dist, rank, world, args.syncbn_size, args.syncbn_batch, args.classes,
                             args.train_steps, args.warmup, syncbn=True, overlap=True, allreduce_alone=False)
@@ -701,11 +716,12 @@ def bench_train(args, vy, dev, dist, rank, world, traffic=None, traffic_note=Non
     """--mode train: BASELINE configs[2]/[4] as the headline line (see train_leg)."""
     leg = train_leg(vy, dev, dist, rank, world, args.size, args.batch, args.classes, args.steps, args.warmup,
                     syncbn=args.syncbn, overlap=not args.no_overlap, split=not args.no_roofline,
-                    allreduce_alone=not args.no_roofline)
+                    allreduce_alone=not args.no_roofline, conv_mode=args.conv_mode)
     result = {
         "metric": "frames/sec, yolo3_darknet53 training %dx%d" % (args.size, args.size),
         "value": leg["frames_per_s"], "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": leg["ms_per_step"], "higher_is_better": True, "scaling": "weak",
+        "conv_mode": args.conv_mode,
         "vs_baseline": None, "dtype": "f32" if args.conv_mode == "exact" else SPLIT_DTYPE, "data": "synthetic",
         "config": {"workload": "BASELINE.json configs[%d]: training step, VOC-shape synthetic (%d cls, 8 gt/img), "
                                "%dx%d, per-GPU batch %d, SGD(1e-3, 0.9, 5e-4), %s BN, gradient all-reduce over %d rank(s)"

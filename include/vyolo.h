@@ -121,14 +121,18 @@ int vy_net_set_keep_activations(vy_net* net, int32_t keep);
  * hard-part (iii) admits "split-fp32").  No counterpart in the reference: mxnet picks its conv algorithm itself.
  *   VY_CONV_EXACT_FP32     default, the parity path: every output one fp32 fma chain on v_mfma_f32_32x32x2_f32,
  *                          bit-identical to oracle/ 
- *   VY_CONV_SPLIT_BF16X3   opt-in: the 3x3 cells with cout % 128 == 0 run on the bf16 matrix core — every fp32
- *                          operand cut exactly into three bf16 numbers, six partial products per multiply, fp32
- *                          accumulation (csrc/conv_split.hip); NOT bit-equal to the exact path (tolerances:
- *                          tests/test_gpu_split.py), 1.4-1.5x faster on those layers.  Planes, stem, 1x1 convs,
- *                          decode and NMS are shared with the exact path.  Training always runs the exact kernels.
+ *   VY_CONV_SPLIT_BF16X3   opt-in, INFERENCE: every conv+BN+leaky cell with cout % 64 == 0 whose launch is large enough
+ *                          (per-launch cost model) runs on the bf16 matrix core — every fp32 operand cut exactly into
+ *                          three bf16 numbers, six partial products per multiply, fp32 accumulation
+ *                          (csrc/conv_split.hip); NOT bit-equal to the exact path (tolerances:
+ *                          tests/test_gpu_split.py), 1.3x the frames/s at 608x608 batch 64.  Planes, stem, prediction
+ *                          convs, decode and NMS are shared with the exact path.  Training runs the exact kernels.
+ *   VY_CONV_SPLIT_BF16X3_TRAIN   as above, and the recorded forward and the data gradients of TRAINING too (weight
+ *                          gradients stay exact).  Experimental: correct (same tests), but no faster at 416x416 batch 16 —
+ *                          the step is bound by the weight gradients.
  * Changes the plan (the pre-split weight images live in the workspace): call before vy_net_workspace_bytes /
  * vy_net_bind_workspace; a bound workspace is unbound by a change. */
-enum vy_conv_mode { VY_CONV_EXACT_FP32 = 0, VY_CONV_SPLIT_BF16X3 = 1 };
+enum vy_conv_mode { VY_CONV_EXACT_FP32 = 0, VY_CONV_SPLIT_BF16X3 = 1, VY_CONV_SPLIT_BF16X3_TRAIN = 2 };
 int vy_net_set_conv_mode(vy_net* net, int32_t mode);
 int32_t vy_net_get_conv_mode(const vy_net* net);
 /* The weight images of VY_CONV_SPLIT_BF16X3 are rebuilt by the next inference forward after any parameter write the

@@ -209,7 +209,7 @@ def test_default_policy_keeps_small_launches_exact(voc_classes, synth20, monkeyp
     n1 = sum("|split" in n for n in _split_launches(net, frames(1, 416)))
     x16 = frames(16, 416, seed=3)
     n16 = sum("|split" in n for n in _split_launches(net, x16))
-    assert n1 < n16 and n1 <= 45 and n16 >= 60, (n1, n16)
+    assert n1 < n16 and n1 <= 45 and n16 >= 50, (n1, n16)
     assert any("k" in n.split("|split")[1] for n in _split_launches(net, frames(1, 416)) if "|split" in n)   # split-K is in use
     net(x16[:2])
     ref = _oracle(synth20).raw_heads(x16[:2])
@@ -285,3 +285,118 @@ def test_split_hybridized_and_two_streams(voc_classes, synth20):
     c = [t.cpu().numpy() for t in net(x, return_index=True)]
     for u, v, w in zip(a, b, c):
         assert np.array_equal(u, v) and np.array_equal(u, w)
+
+
+def _train_case(C, B, S):
+    from videoyolo_amd import init
+    from oracle import targets_oracle as T
+    from oracle import yolo3_oracle as O
+    params = init.synthetic_params(O.param_shapes(C), seed=11)
+    x = frames(B, S, seed=5)
+    gt_boxes, gt_ids = T.synthetic_gt(B, S, C, m=3, seed=2, pad_to=5)
+    tg = T.prefetch_targets(C, S, S, gt_boxes, gt_ids)
+    return params, x, gt_boxes, tg
+
+
+def _step(net, x, gt_boxes, tg):
+    from videoyolo_amd import autograd
+    with autograd.record():
+        losses = net(x, gt_boxes, *tg)
+        autograd.backward([losses[0] + losses[1] + losses[2] + losses[3]])
+    grads = {p.name: net.grad(p.name) for p in net.collect_params().values() if p.trainable}
+    return [l.cpu().numpy() for l in losses], grads
+
+
+def _rel_l2(a, b):
+    return float(np.linalg.norm(a.astype(np.float64) - b.astype(np.float64)) / (np.linalg.norm(b.astype(np.float64)) + 1e-30))
+
+
+@pytest.mark.parametrize("C,B,S", [(20, 2, 256), (4, 2, 128)])
+def test_split_training_step_within_the_steps_own_sensitivity(C, B, S, capsys):
+    """conv mode 'split_bf16x3' in TRAINING: the recorded forward (raw conv + per-tile batch statistics in double) and
+    the data gradients run on the split kernel; weight gradients stay exact.  Losses: 1e-4 against the oracle, as for the
+    exact path.  Gradients need a different yardstick than the exact path's 2e-3 of the tensor's max: that bar is met
+    there only because the exact forward is BIT-equal to the oracle's, so every LeakyReLU branch (|y| within 1e-5 of the
+    kink: ~25 per million activations) and every ignore-mask decision comes out the same.  Any forward that differs in
+    the last bits flips a few of them, each flip changes a local gradient by 90 %, and the change spreads upstream: the
+    EXACT path itself, fed the same frames scaled by (1 + 2^-22), moves its own parameter gradients by 1-2e-2 in relative
+    L2 and ~1e-1 of a tensor's max (measured: tools/dbg_split_train.py).  So: the split step's distance to the oracle must
+    stay within 3x the distance the exact path's own one-ulp-perturbed step has — per tensor class, in relative L2."""
+    import videoyolo_amd as vy
+    from oracle import yolo3_train_oracle as TO
+    params, x, gt_boxes, tg = _train_case(C, B, S)
+    orc = TO.OracleYolo3Train(C, dict(params))
+    ref_losses = orc.forward_train(x, gt_boxes, *tg)
+    ref_grads = orc.backward()
+    classes = ["c%d" % i for i in range(C)]
+    l_split, g_split = _step(_net(classes, params, mode="split_bf16x3_train"), x, gt_boxes, tg)
+    for got, want in zip(l_split, ref_losses):
+        np.testing.assert_allclose(got, want, rtol=1e-4, atol=1e-4)
+    exact = _net(classes, params, mode="exact")
+    _, g_exact = _step(exact, x, gt_boxes, tg)
+    _, g_pert = _step(exact, (x * np.float32(1.0 + 2.0 ** -22)).astype(np.float32), gt_boxes, tg)
+    d_exact = max(_rel_l2(g_exact[k], ref_grads[k]) for k in ref_grads)
+    d_pert = max(_rel_l2(g_pert[k], ref_grads[k]) for k in ref_grads)
+    d_split = max(_rel_l2(g_split[k], ref_grads[k]) for k in ref_grads)
+    with capsys.disabled():
+        print("\n[train C=%d B=%d %d^2] worst relative L2 of a parameter gradient against the oracle: exact %.2e | exact on "
+              "frames x (1 + 2^-22) %.2e | split %.2e" % (C, B, S, d_exact, d_pert, d_split))
+    assert d_exact < 2e-3                      # the parity path itself
+    assert d_split <= 3 * d_pert + 1e-3        # the split step is as far from the oracle as a one-ulp change of the input is
+    assert d_split < 0.1
+
+
+def test_split_data_gradients_alone_meet_the_exact_bars():
+    """VY_SPLIT_TRAIN=3 (own process: the switch is read once): forward EXACT — bit-equal to the oracle, so no branch
+    flips — and the data gradients on the split kernel (its [k = cout][n = cin] weight images, flipped taps, the four
+    parity classes of the stride-2 convs, cout = 3 (5 + C) zero-padded to 32 for the prediction convs, accumulate into
+    a skip gradient).  Then the exact path's own bars hold: losses 1e-4, every gradient within 2e-3 of its tensor's max."""
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    code = (
+        "import sys, json; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import numpy as np\n"
+        "import test_gpu_split as t\n"
+        "from oracle import yolo3_train_oracle as TO\n"
+        "worst = 0.0\n"
+        "for C, B, S in [(20, 2, 96), (80, 1, 96), (4, 2, 64)]:\n"
+        "    params, x, gt, tg = t._train_case(C, B, S)\n"
+        "    orc = TO.OracleYolo3Train(C, dict(params)); rl = orc.forward_train(x, gt, *tg); rg = orc.backward()\n"
+        "    l, g = t._step(t._net(['c%%d' %% i for i in range(C)], params, mode='split_bf16x3_train'), x, gt, tg)\n"
+        "    assert all(np.allclose(a, b, rtol=1e-4, atol=1e-4) for a, b in zip(l, rl))\n"
+        "    worst = max(worst, max(float(np.abs(g[k] - rg[k]).max() / (np.abs(rg[k]).max() + 1e-6)) for k in rg))\n"
+        "print('RESULT', json.dumps({'worst': worst}))\n") % (here, os.path.dirname(here))
+    env = dict(os.environ, VY_SPLIT_TRAIN="3", VY_SPLIT_ALWAYS="1")
+    p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    import json
+    r = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("RESULT ")][-1][7:])
+    assert r["worst"] < 2e-3, r
+
+
+def test_split_training_equals_exact_training_when_switched_off(voc_classes, synth20, monkeypatch):
+    """The mode switch itself: 'split_bf16x3' (inference only) and 'exact' train bit-identically to a net that never
+    left the exact mode; 'split_bf16x3_train' really is a different summation."""
+    from videoyolo_amd import autograd
+    from oracle import targets_oracle as T
+    x = frames(2, 64, seed=9)
+    gt_boxes, gt_ids = T.synthetic_gt(2, 64, 20, m=3, seed=2, pad_to=5)
+    tg = T.prefetch_targets(20, 64, 64, gt_boxes, gt_ids)
+
+    def step(net):
+        with autograd.record():
+            l = net(x, gt_boxes, *tg)
+            autograd.backward([l[0] + l[1] + l[2] + l[3]])
+        return [t.cpu().numpy() for t in l], net._grads.cpu().numpy().copy()
+    a = _net(voc_classes, synth20, mode="exact")
+    la, ga = step(a)
+    b = _net(voc_classes, synth20, mode="split_bf16x3_train")
+    lb, gb = step(b)
+    b.set_conv_mode("split_bf16x3")         # the inference-only mode trains on the exact kernels
+    ld, gd = step(b)
+    assert all(np.array_equal(u, v) for u, v in zip(la, ld)) and np.array_equal(ga, gd)
+    b.set_conv_mode("exact")
+    lc, gc = step(b)
+    assert all(np.array_equal(u, v) for u, v in zip(la, lc)) and np.array_equal(ga, gc)
+    assert not np.array_equal(ga, gb)       # the split step really was a different summation

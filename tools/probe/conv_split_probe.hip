@@ -41,6 +41,7 @@ int main(int argc, char** argv) {
   const int B = atoi(argv[1]), H = atoi(argv[2]), Cin = atoi(argv[3]), Cout = atoi(argv[4]), k = atoi(argv[5]);
   const int stride = argc > 6 ? atoi(argv[6]) : 1, res = argc > 7 ? atoi(argv[7]) : 0;
   const int reps = argc > 8 ? atoi(argv[8]) : 20;
+  const int dgrad = getenv("VY_PROBE_DGRAD") ? atoi(getenv("VY_PROBE_DGRAD")) : 0;  // 1: the data gradient of that conv (stride 1)
   const int Ho = (H + stride - 1) / stride;
   const size_t in_n = (size_t)B * (H + 2) * (H + 2) * Cin, out_n = (size_t)B * (Ho + 2) * (Ho + 2) * Cout;
   const size_t w_n = (size_t)Cout * k * k * Cin;
@@ -81,6 +82,12 @@ int main(int argc, char** argv) {
     CK(hipMemcpy(rs, h_rs.data(), out_n * 4, hipMemcpyHostToDevice));
   }
   CK(vy_launch_split_weights(w, wimg, Cout, k * k, Cin, 0));
+  void* wimg_d = nullptr;
+  if (dgrad) {
+    if (stride != 1 || H != Ho) return fprintf(stderr, "dgrad probe: stride 1 only\n"), 2;
+    CK(hipMalloc(&wimg_d, vy_split_weight_dgrad_bytes(Cout, k * k, Cin)));
+    CK(vy_launch_split_weights_dgrad(w, wimg_d, Cout, k * k, Cin, 0));
+  }
   ConvArgs a;
   memset(&a, 0, sizeof a);
   a.in = in; a.w = w; a.scale = sc; a.shift = sh; a.res = rs; a.out = out;
@@ -109,8 +116,31 @@ int main(int argc, char** argv) {
     a.splitk_slabs = (float*)slabs;
     a.splitk_bytes = VY_SK_PARTIAL_BYTES;
   }
+  float *dz = nullptr, *gin = nullptr, *gin2 = nullptr;
+  if (dgrad) {  // dz = the forward probe's input tensor reinterpreted is no use (channel counts differ): own planes
+    const size_t dz_n = (size_t)B * (H + 2) * (H + 2) * Cout, g_n = (size_t)B * (H + 2) * (H + 2) * Cin;
+    std::vector<float> h_dz(dz_n);
+    fill_normal(h_dz, 1.0f, 31337ull);
+    for (int b = 0; b < B; ++b)
+      for (int y = 0; y < H + 2; ++y)
+        for (int x = 0; x < H + 2; ++x)
+          if (y == 0 || x == 0 || y == H + 1 || x == H + 1) memset(&h_dz[(((size_t)b * (H + 2) + y) * (H + 2) + x) * Cout], 0, Cout * 4);
+    CK(hipMalloc(&dz, dz_n * 4));
+    CK(hipMalloc(&gin, g_n * 4));
+    CK(hipMalloc(&gin2, g_n * 4));
+    CK(hipMemcpy(dz, h_dz.data(), dz_n * 4, hipMemcpyHostToDevice));
+    CK(hipMemset(gin, 0, g_n * 4));
+    CK(hipMemset(gin2, 0, g_n * 4));
+    a.in = dz; a.scale = nullptr; a.shift = nullptr; a.res = nullptr; a.out = gin; a.leaky = 0; a.dgrad = 1;
+    a.a_cs = Cout; a.Kc = (Cout + 31) & ~31; a.N = Cin; a.o_cs = Cin; a.r_cs = Cin;
+    for (int t = 0; t < a.ntaps; ++t) {
+      a.tap_dy[t] = (signed char)(k == 3 ? 1 - t / 3 : 0);
+      a.tap_dx[t] = (signed char)(k == 3 ? 1 - t % 3 : 0);
+    }
+    a.w_split = wimg_d;
+  }
   ConvArgs a2 = a;
-  a2.out = out2;
+  a2.out = dgrad ? gin2 : out2;
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0));
   CK(hipEventCreate(&e1));
@@ -137,18 +167,20 @@ int main(int argc, char** argv) {
            B, H, Cin, Cout, k, stride, res, a.M, a.N, K, us_e, gflop / us_e * 1e3, us_s, gflop / us_s * 1e3,
            6 * gflop / us_s * 1e3, us_e / us_s);
   }
-  std::vector<float> o1(out_n), o2(out_n);
-  CK(hipMemcpy(o1.data(), out, out_n * 4, hipMemcpyDeviceToHost));
-  CK(hipMemcpy(o2.data(), out2, out_n * 4, hipMemcpyDeviceToHost));
+  const size_t cmp_n = dgrad ? (size_t)B * (H + 2) * (H + 2) * Cin : out_n;
+  std::vector<float> o1(cmp_n), o2(cmp_n);
+  CK(hipMemcpy(o1.data(), dgrad ? gin : out, cmp_n * 4, hipMemcpyDeviceToHost));
+  CK(hipMemcpy(o2.data(), dgrad ? gin2 : out2, cmp_n * 4, hipMemcpyDeviceToHost));
   double maxd = 0, maxv = 0;
   size_t nbad = 0;
-  for (size_t i = 0; i < out_n; ++i) {
+  for (size_t i = 0; i < cmp_n; ++i) {
     const double d = fabs((double)o1[i] - (double)o2[i]);
     if (!(d <= 1e30)) ++nbad;
     if (d > maxd) maxd = d;
     if (fabs(o1[i]) > maxv) maxv = fabs(o1[i]);
   }
   printf("  split vs exact: max |diff| %.3e  (max |value| %.3f, non-finite %zu)\n", maxd, maxv, nbad);
+  if (dgrad) return 0;
   // float64 reference on sampled outputs
   double err_e = 0, err_s = 0;
   unsigned long long st = 424242ull;

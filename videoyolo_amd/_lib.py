@@ -7,7 +7,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libvyolo.so")
 
 VY_MAX_TOPK = 1024
-VY_CONV_EXACT_FP32, VY_CONV_SPLIT_BF16X3 = 0, 1
+VY_CONV_EXACT_FP32, VY_CONV_SPLIT_BF16X3, VY_CONV_SPLIT_BF16X3_TRAIN = 0, 1, 2
 
 
 class VyError(RuntimeError):

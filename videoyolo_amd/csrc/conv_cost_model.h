@@ -100,7 +100,8 @@ static const VySplitModel kVySplitModels[3] = {{128, 128, 0.0372, 3.0, 1.10}, {1
 // k-split S > 1 (at most max_ksplit: what the slab scratch holds): tiles x S blocks of K / S each plus the finish
 // launch — for launches that leave most CUs without a block (a single frame's 19x19 layer: 24 tiles of 288 k-steps).
 // Fitted on tools/probe/run_split_ksplit_sweep.sh: the second launch, the slab round trip and the short k-loops'
-// pipeline fill cost about 8 us (19x19, K = 4608, one frame: 190 us unsplit, 36.7 us as 8 slices; the exact kernel 75 us).
+// pipeline fill cost about 9 us (19x19, K = 4608, one frame: 190 us unsplit, 36.7 us as 8 slices; the exact kernel 75 us);
+// every launch carries 4 us of fill / drain (a single frame's 152x152 layers: 38.6 us on 181 lone blocks, the exact kernel 34.3).
 inline double vy_predict_split(long long M, int N, double K, int max_ksplit, int* bm, int* bn, int* ksplit) {
   double best = 1e300;
   *ksplit = 1;
@@ -114,7 +115,8 @@ inline double vy_predict_split(long long M, int N, double K, int max_ksplit, int
       const long long blocks = tiles * S;
       double t = (double)((blocks + 255) / 256) * (c.alpha * K / S + c.fixed);
       if (blocks <= 256) t *= c.lone;
-      if (S > 1) t += 8.0;
+      t += 4.0;               // per launch: pipeline fill and drain of a kernel that prefetches two k-steps ahead
+      if (S > 1) t += 5.0;    // the finish launch and the slab round trip
       if (t < best * 0.995) {
         best = t;
         *bm = c.bm;

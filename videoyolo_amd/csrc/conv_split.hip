@@ -103,6 +103,101 @@ __global__ void split_weights_kernel(const float* __restrict__ w, unsigned short
   }
 }
 
+// the same weights as the [k = cout][n = cin] operand of the data gradient (train_yolov3.py:631 through Convolution's
+// backward): image rows = input channels, k-steps = (tap, 16 output channels), cout zero-padded to a multiple of 32
+// (the prediction convs: 75 -> 96; the dz planes' padding channels are zero as well)
+__global__ void split_weights_dgrad_kernel(const float* __restrict__ w, unsigned short* __restrict__ img, const int cout,
+                                           const int taps, const int cin) {
+  const int coutp = (cout + 31) & ~31;
+  const long long total = (long long)coutp * taps * cin;
+  const int KS = taps * (coutp >> 4);
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(e % cin);
+    const long long t_ = e / cin;
+    const int tap = (int)(t_ % taps), o = (int)(t_ / taps);
+    const float x = o < cout ? w[e] : 0.0f;
+    auto rne = [](float f) -> unsigned {
+      const unsigned u = __builtin_bit_cast(unsigned, f);
+      return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+    };
+    const unsigned h = rne(x);
+    const float r = x - __builtin_bit_cast(float, h << 16);
+    const unsigned m = rne(r);
+    const float q = r - __builtin_bit_cast(float, m << 16);
+    const unsigned l = rne(q);
+    const int ng = c >> 5, row = c & 31, ks = tap * (coutp >> 4) + (o >> 4), oct = (o >> 3) & 1, j = o & 7;
+    const long long base = (((long long)ng * KS + ks) * 3) * 512 + row * 16 + (VY_SPLIT_SLOT(row, oct) << 3) + j;
+    img[base] = (unsigned short)h;
+    img[base + 512] = (unsigned short)m;
+    img[base + 1024] = (unsigned short)l;
+  }
+}
+
+size_t vy_split_weight_dgrad_bytes(int cout, int taps, int cin) {
+  return (size_t)((cin + 31) / 32) * taps * (((cout + 31) & ~31) / 16) * 3072;
+}
+
+hipError_t vy_launch_split_weights_dgrad(const float* w, void* img, int cout, int taps, int cin, hipStream_t s) {
+  if (cin % 32 != 0) return hipErrorInvalidValue;
+  const long long total = (long long)((cout + 31) & ~31) * taps * cin;
+  const int blocks = (int)std::min<long long>((total + 255) / 256, 8192);
+  hipLaunchKernelGGL(split_weights_dgrad_kernel, dim3(blocks), dim3(256), 0, s, w, (unsigned short*)img, cout, taps, cin);
+  return hipGetLastError();
+}
+
+// Every conv's images in ONE launch (the per-conv launches above cost 70 x 2 kernel boundaries per training step):
+// descriptors sorted by `first` (prefix sum of the element counts); a thread finds its conv by bisection.
+__global__ __launch_bounds__(256) void split_weights_batch_kernel(const float* __restrict__ params, unsigned char* __restrict__ ws,
+                                                                  const SplitDesc* __restrict__ d, const int n,
+                                                                  const long long total) {
+  auto rne = [](float f) -> unsigned {
+    const unsigned u = __builtin_bit_cast(unsigned, f);
+    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+  };
+  for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long long)gridDim.x * blockDim.x) {
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (d[mid].first <= g) lo = mid;
+      else hi = mid - 1;
+    }
+    const SplitDesc c = d[lo];
+    const long long e = g - c.first;
+    const int cin = c.cin, taps = c.taps;
+    const int ci = (int)(e % cin);
+    const long long t_ = e / cin;
+    const int tap = (int)(t_ % taps), o = (int)(t_ / taps);
+    const float x = o < c.cout ? params[c.w_off + e] : 0.0f;
+    const unsigned h = rne(x);
+    const float r = x - __builtin_bit_cast(float, h << 16);
+    const unsigned m = rne(r);
+    const float q = r - __builtin_bit_cast(float, m << 16);
+    const unsigned l = rne(q);
+    unsigned short* img = reinterpret_cast<unsigned short*>(ws + c.img_off);
+    long long base;
+    if (!c.dgrad) {
+      const int KS = taps * (cin >> 4);
+      const int ng = o >> 5, row = o & 31, ks = tap * (cin >> 4) + (ci >> 4), oct = (ci >> 3) & 1, j = ci & 7;
+      base = (((long long)ng * KS + ks) * 3) * 512 + row * 16 + (VY_SPLIT_SLOT(row, oct) << 3) + j;
+    } else {
+      const int coutp = (c.cout + 31) & ~31, KS = taps * (coutp >> 4);
+      const int ng = ci >> 5, row = ci & 31, ks = tap * (coutp >> 4) + (o >> 4), oct = (o >> 3) & 1, j = o & 7;
+      base = (((long long)ng * KS + ks) * 3) * 512 + row * 16 + (VY_SPLIT_SLOT(row, oct) << 3) + j;
+    }
+    img[base] = (unsigned short)h;
+    img[base + 512] = (unsigned short)m;
+    img[base + 1024] = (unsigned short)l;
+  }
+}
+
+hipError_t vy_launch_split_weights_batch(const float* params, void* ws, const SplitDesc* descs_dev, int n, long long total,
+                                         hipStream_t s) {
+  if (n < 1 || total < 1) return hipSuccess;
+  const int blocks = (int)std::min<long long>((total + 255) / 256, 16384);
+  hipLaunchKernelGGL(split_weights_batch_kernel, dim3(blocks), dim3(256), 0, s, params, (unsigned char*)ws, descs_dev, n, total);
+  return hipGetLastError();
+}
+
 size_t vy_split_weight_bytes(int cout, int taps, int cin) { return (size_t)((cout + 31) / 32) * taps * (cin / 16) * 3072; }
 
 hipError_t vy_launch_split_weights(const float* w, void* img, int cout, int taps, int cin, hipStream_t s) {
@@ -483,8 +578,8 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(const ConvArgs a, co
   const __amdgpu_buffer_rsrc_t res_rsrc = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(a.res ? a.res + (pix0 * a.r_cs + a.r_co + n0) : a.in), 0, 0x7fffffff, kRsrcFlags);
   const int ups_dx = a.o_cs * 4, ups_dy = a.o_Wp * a.o_cs * 4;
-  auto epilogue = [&](auto has_scale_, auto leaky_, auto has_res_, auto ups2_) {
-    constexpr bool has_scale = decltype(has_scale_)::value;
+  auto epilogue = [&](auto has_scale_, auto has_shift_, auto leaky_, auto has_res_, auto ups2_) {
+    constexpr bool has_scale = decltype(has_scale_)::value, has_shift = decltype(has_shift_)::value;
     constexpr bool leaky = decltype(leaky_)::value, has_res = decltype(has_res_)::value, ups2 = decltype(ups2_)::value;
 #pragma unroll
     for (int j = 0; j < TNs; ++j) {
@@ -496,7 +591,7 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(const ConvArgs a, co
       const unsigned colc = (unsigned)ncol * 4u | (nvalid ? 0u : kInvalidRow);
       float sc = 1.0f, sh = 0.0f;
       if (has_scale) sc = a.scale[nc];
-      sh = a.shift[nc];
+      if (has_scale || has_shift) sh = a.shift[nc];
 #pragma unroll
       for (int i = 0; i < TMs; ++i) {
         unsigned oo[NR];
@@ -512,7 +607,7 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(const ConvArgs a, co
           float vv = acc[i][j][r];
           if (has_scale)
             vv = fmaf(vv, sc, sh);
-          else
+          else if (has_shift)
             vv = vv + sh;
           if (leaky) vv = vy_leaky(vv);
           if (has_res) vv = vv + rv[r];
@@ -533,32 +628,86 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(const ConvArgs a, co
   {
     using T_ = std::true_type;
     using F_ = std::false_type;
-    const bool f_scale = a.scale != nullptr, f_leaky = a.leaky != 0, f_res = a.res != nullptr, f_ups2 = a.ups == 2;
-    if (f_scale && f_leaky && !f_ups2) {
-      if (f_res) epilogue(T_{}, T_{}, T_{}, F_{});
-      else epilogue(T_{}, T_{}, F_{}, F_{});
-    } else if (f_scale && f_leaky && !f_res) {
-      epilogue(T_{}, T_{}, F_{}, T_{});
-    } else if (!f_scale && !f_leaky && !f_ups2 && !f_res) {
-      epilogue(F_{}, F_{}, F_{}, F_{});  // bias only (prediction convs)
+    const bool f_scale = a.scale != nullptr, f_shift = a.shift != nullptr, f_leaky = a.leaky != 0;
+    const bool f_res = a.res != nullptr, f_ups2 = a.ups == 2;
+    if (f_scale && f_shift && f_leaky && !f_ups2) {            // conv + BN + leaky (+ residual): inference cells
+      if (f_res) epilogue(T_{}, T_{}, T_{}, T_{}, F_{});
+      else epilogue(T_{}, T_{}, T_{}, F_{}, F_{});
+    } else if (f_scale && f_shift && f_leaky && !f_res) {      // transition cells: x2-replicated store
+      epilogue(T_{}, T_{}, T_{}, F_{}, T_{});
+    } else if (!f_scale && !f_leaky && !f_ups2) {              // raw conv (training forward) / bias / gradients (+ accumulate)
+      if (f_shift) {
+        if (f_res) epilogue(F_{}, T_{}, F_{}, T_{}, F_{});
+        else epilogue(F_{}, T_{}, F_{}, F_{}, F_{});
+      } else {
+        if (f_res) epilogue(F_{}, F_{}, F_{}, T_{}, F_{});
+        else epilogue(F_{}, F_{}, F_{}, F_{}, F_{});
+      }
     } else {
       __builtin_trap();
+    }
+  }
+  // train-mode BatchNorm: per-tile column sums of the raw accumulators in double, as conv_igemm.hip writes them
+  // ([tile_m][2][N]; fixed order inside the tile, tiles combined in order by the finalize kernel)
+  if constexpr (!M16) {
+    if (a.stats) {
+      double s1[TNs], s2[TNs];
+#pragma unroll
+      for (int j = 0; j < TNs; ++j) {
+        s1[j] = 0.0;
+        s2[j] = 0.0;
+#pragma unroll
+        for (int i = 0; i < TMs; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = wm * (BM / WM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            const double vv = o_off[row] != kInvalidRow ? (double)acc[i][j][r] : 0.0;
+            s1[j] += vv;
+            s2[j] += vv * vv;
+          }
+        s1[j] += __shfl_xor(s1[j], 32);
+        s2[j] += __shfl_xor(s2[j], 32);
+      }
+      __syncthreads();  // every wave is past its last LDS tile read
+      double* red = reinterpret_cast<double*>(smem);  // [WM][2][BN]
+      if (h == 0) {
+#pragma unroll
+        for (int j = 0; j < TNs; ++j) {
+          const int col = wn * (BN / WN) + j * 32 + lrow;
+          red[(wm * 2 + 0) * BN + col] = s1[j];
+          red[(wm * 2 + 1) * BN + col] = s2[j];
+        }
+      }
+      __syncthreads();
+      if (tid < BN && n0 + tid < a.N) {
+        double t1 = 0.0, t2 = 0.0;
+#pragma unroll
+        for (int w = 0; w < WM; ++w) {
+          t1 += red[(w * 2 + 0) * BN + tid];
+          t2 += red[(w * 2 + 1) * BN + tid];
+        }
+        a.stats[((long long)tile_m * 2 + 0) * a.N + n0 + tid] = t1;
+        a.stats[((long long)tile_m * 2 + 1) * a.N + n0 + tid] = t2;
+      }
     }
   }
 #endif
 }
 
 bool vy_conv_split_supported(const ConvArgs& a) {
-  if (a.dgrad || a.stats || !a.w_split || !a.shift) return false;
+  if (!a.w_split) return false;
+  if (a.stats && VY_SPLIT_M16) return false;
   if (a.Kc % 32 != 0 || a.N % 64 != 0 || a.ntaps < 1 || a.ntaps > 9) return false;
-  const bool bn_cell = a.scale && a.leaky, bias = !a.scale && !a.leaky && !a.res && a.ups != 2;
-  return (bn_cell && (a.ups != 2 || !a.res)) || bias;
+  // epilogues the kernel instantiates (the exact kernel's set): BN cell (+ residual | x2-replicated), or plain
+  // (raw / bias / gradient, + accumulate)
+  const bool bn_cell = a.scale && a.shift && a.leaky, plain = !a.scale && !a.leaky;
+  return (bn_cell && (a.ups != 2 || !a.res)) || (plain && a.ups != 2);
 }
 
 // block tile and k-split of a launch: the cost model's choice (conv_cost_model.h) among 128x128, 128x64 and, for the
 // 64-channel layers, 256x64; k-split > 1 only where the slabs fit the scratch the net provides
 static long long split_max_ksplit(const ConvArgs& a) {
-  if (!a.splitk_slabs) return 1;
+  if (!a.splitk_slabs || a.stats) return 1;  // (the per-tile statistics need whole sums)
   return std::max<long long>(1, (long long)(a.splitk_bytes / ((unsigned long long)a.M * a.N * 4ull)));
 }
 
@@ -610,7 +759,8 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(const ConvArgs a, co
   const int b = (int)fd_div((unsigned)t, a.fd_lh);
   const int y = t - b * a.LH;
   const long long pix = (long long)(b * a.o_Hp + y * a.o_s + a.o_oy) * a.o_Wp + x * a.o_s + a.o_ox;
-  const f32x4 sh = *reinterpret_cast<const f32x4*>(a.shift + n);
+  f32x4 sh = {0.f, 0.f, 0.f, 0.f};
+  if (a.shift) sh = *reinterpret_cast<const f32x4*>(a.shift + n);
   if (a.scale) {
     const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scale + n);
 #pragma unroll
@@ -664,11 +814,13 @@ hipError_t vy_launch_conv_split(const ConvArgs& a_in, hipStream_t s) {
   }
   int bm, bn, ks;
   vy_conv_split_cfg(a, &bm, &bn, &ks);
-  // the deep-pipeline instance where a CU ends up with one block (128x128: its 98 KiB of LDS allow no second one anyway)
-  // or two short-lived ones (128x64)
-  static const int deep_sw = getenv("VY_SPLIT_DEEP") ? atoi(getenv("VY_SPLIT_DEEP")) : -1;  // experiments: 0 never, 1 always
+  // The deep-pipeline instance (loads three k-steps ahead) was built for launches that leave a CU with one block and
+  // measured NO faster than the plain one on any single-frame layer (19x19 K = 4608 as 10 slices: 33.4 vs 32.5 us, 38x38:
+  // 34.0 vs 33.3, 1x1 layers 1-5 % slower; profiles/r04_negative_results.txt section 3): those launches are bound by
+  // their fixed parts (two launches, prologue, slab round trip), not by load latency.  OFF; VY_SPLIT_DEEP=1 for experiments.
+  static const int deep_sw = getenv("VY_SPLIT_DEEP") ? atoi(getenv("VY_SPLIT_DEEP")) : 0;
   const long long blocks = (long long)((a.M + bm - 1) / bm) * (a.N / bn) * ks;
-  const bool deep = deep_sw >= 0 ? deep_sw != 0 : blocks <= (bn == 128 ? 256 : 512);
+  const bool deep = deep_sw != 0 && blocks <= (bn == 128 ? 256 : 512);
   if (bm == 128 && bn == 128) return deep ? launch_split<128, 128, 4, true>(a, ks, s) : launch_split<128, 128, 3>(a, ks, s);
   if (bm == 256 && bn == 64) return launch_split<256, 64, 2>(a, ks, s);
   if (bm == 128 && bn == 64) return deep ? launch_split<128, 64, 4, true>(a, ks, s) : launch_split<128, 64, 3>(a, ks, s);

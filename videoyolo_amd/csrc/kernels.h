@@ -79,6 +79,19 @@ int vy_sk_verify_topology(unsigned* scratch_dev, hipStream_t s);
 // Same ConvArgs / planes as vy_launch_conv_igemm, plus a.w_split = the conv's weights as bf16 tile images.
 size_t vy_split_weight_bytes(int cout, int taps, int cin);
 hipError_t vy_launch_split_weights(const float* w, void* img, int cout, int taps, int cin, hipStream_t s);
+// ... and as the [k = cout][n = cin] operand of the data gradient (cin % 32 == 0; cout zero-padded to 32)
+size_t vy_split_weight_dgrad_bytes(int cout, int taps, int cin);
+hipError_t vy_launch_split_weights_dgrad(const float* w, void* img, int cout, int taps, int cin, hipStream_t s);
+// all images of a net in one launch: descriptors (device memory, sorted by `first`) of `n` image sets covering `total`
+// weight elements (dgrad sets count their zero-padded cout); params / ws: the parameter buffer and the workspace
+struct SplitDesc {
+  long long first;     // index of this set's first element in the launch's flat element range
+  long long w_off;     // element offset of the conv's weights in the parameter buffer
+  long long img_off;   // byte offset of the images in the workspace
+  int cout, taps, cin, dgrad;
+};
+hipError_t vy_launch_split_weights_batch(const float* params, void* ws, const SplitDesc* descs_dev, int n, long long total,
+                                         hipStream_t s);
 bool vy_conv_split_supported(const ConvArgs& a);   // forward, N % 64 == 0, Kc % 32 == 0, an epilogue the kernel has
 void vy_conv_split_cfg(const ConvArgs& a, int* bm, int* bn, int* ksplit);  // block tile and k-split the launch will use
 // conv mode VY_CONV_SPLIT_BF16X3, per launch: supported AND predicted faster than the exact kernel (small launches —

@@ -84,7 +84,8 @@ struct vy_net {
   bool sk_ok = false;
   bool sk_dirty = false;
   int conv_mode = 0;
-  bool split_dirty = true;
+  bool split_dirty = true;    // the forward weight images are stale
+  bool dsplit_dirty = true;   // the data-gradient weight images (training plans; train.hip) are stale
   size_t wsplit_off = 0;
   struct VyTrain* train = nullptr;  // training planner state, owned by train.hip
 
@@ -263,7 +264,7 @@ struct vy_net {
   // (75 channels) stay on the exact kernel.
   bool split_eligible(const ConvT& c) const {
     static const int with_1x1 = getenv("VY_SPLIT_1X1") ? atoi(getenv("VY_SPLIT_1X1")) : 1;
-    if (conv_mode != VY_CONV_SPLIT_BF16X3 || c.is_stem || c.p_gamma < 0) return false;
+    if (conv_mode == VY_CONV_EXACT_FP32 || c.is_stem || c.p_gamma < 0) return false;
     if (c.cout % 64 != 0 || c.cin % 32 != 0) return false;
     return c.k == 3 || with_1x1;
   }
@@ -359,7 +360,7 @@ struct vy_net {
       det_scratch_off = det_off;
       sk_off = sk_o;
       wsplit_off = wsp_off;
-      split_dirty = true;
+      split_dirty = dsplit_dirty = true;
       planes_off = pl_off;
       B = b;
       H = h;
@@ -506,7 +507,7 @@ struct vy_net {
     hook("bn_fold", 0.0, 0.0, true);
     HIP_TRY(vy_launch_bn_fold(dev_params, fd, (int)folds.size(), 1024, 1e-5f, s));
     hook("bn_fold", 0.0, 0.0, false);
-    if (conv_mode == VY_CONV_SPLIT_BF16X3 && split_dirty) {  // once per parameter change, not per forward
+    if (conv_mode != VY_CONV_EXACT_FP32 && split_dirty) {  // once per parameter change, not per forward
       hook("split_weights", 0.0, 0.0, true);
       for (const ConvT& c : convs)
         if (c.split_off >= 0)

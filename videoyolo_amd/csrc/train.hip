@@ -43,6 +43,14 @@ struct VyTrain {
   std::vector<ZPlane> z;               // per conv
   std::vector<size_t> save_idx;        // per conv: float offset of [2][C] saved mean/invstd
   std::vector<int> splits, kps;        // per conv wgrad split-K
+  // conv mode VY_CONV_SPLIT_BF16X3: per conv, byte offset of its weights' DATA-GRADIENT tile images ([k = cout][n = cin]
+  // operand; conv_split.hip) inside the region at dsplit_off, -1: exact kernel.  The forward images are the net's.
+  std::vector<long long> dsplit;
+  size_t dsplit_off = 0;
+  std::vector<SplitDesc> sdesc;        // all image sets (forward + data gradient) for the one-launch rebuild
+  size_t sdesc_off = 0;
+  long long sdesc_total = 0;
+  bool sdesc_uploaded = false;
   std::vector<size_t> tab_off;         // per conv: byte offset of its weight-gradient pixel table in the workspace
   bool tabs_built = false;
   std::vector<SgdSeg> segs;
@@ -125,6 +133,18 @@ VyTrain* get_train(vy_net* net) {
 size_t train_plan(vy_net* net, int b, int h, int w, bool commit) {
   VyTrain* t = get_train(net);
   size_t off = al256(net->plan(b, h, w, commit, /*keep_all=*/true));  // backward reads every activation plane
+  // split-fp32 conv mode: the data gradients whose N (= cin) the split kernel has a tile for get their own weight images
+  std::vector<long long> dsplit(net->convs.size(), -1);
+  const size_t dsplit_off = off;
+  if (net->conv_mode == VY_CONV_SPLIT_BF16X3_TRAIN) {
+    static const int train_split = getenv("VY_SPLIT_TRAIN") ? atoi(getenv("VY_SPLIT_TRAIN")) : 1;
+    for (size_t i = 0; i < net->convs.size() && train_split; ++i) {
+      const ConvT& c = net->convs[i];
+      if (c.is_stem || c.cin % 64 != 0) continue;
+      dsplit[i] = (long long)(off - dsplit_off);
+      off += al256(vy_split_weight_dgrad_bytes(c.cout, c.k * c.k, c.cin));
+    }
+  }
   // gradient planes mirror the activation planes
   size_t gfl = 0;
   for (auto& p : net->planes) gfl += ((size_t)b * (h / p.div + 2) * (w / p.div + 2) * p.C + 63) & ~(size_t)63;
@@ -258,6 +278,8 @@ size_t train_plan(vy_net* net, int b, int h, int w, bool commit) {
     tab_off[i] = off;
     off += al256(vy_wgrad_table_entries(M) * 8);
   }
+  const size_t sdesc_off = off;
+  off += al256(sizeof(SplitDesc) * 2 * net->convs.size());
   const size_t seg_off = off;
   off += al256(segs.size() * sizeof(SgdSeg));
   const size_t chunk_off = off;
@@ -285,6 +307,24 @@ size_t train_plan(vy_net* net, int b, int h, int w, bool commit) {
     t->save_idx = save;
     t->splits = splits;
     t->kps = kps;
+    t->dsplit = dsplit;
+    t->dsplit_off = dsplit_off;
+    t->sdesc.clear();
+    t->sdesc_total = 0;
+    for (size_t i = 0; i < net->convs.size(); ++i) {
+      const ConvT& c = net->convs[i];
+      const long long w_off = net->params[c.p_weight].info.offset;
+      if (c.split_off >= 0) {
+        t->sdesc.push_back(SplitDesc{t->sdesc_total, w_off, (long long)(net->wsplit_off + c.split_off), c.cout, c.k * c.k, c.cin, 0});
+        t->sdesc_total += (long long)c.cout * c.k * c.k * c.cin;
+      }
+      if (dsplit[i] >= 0) {
+        t->sdesc.push_back(SplitDesc{t->sdesc_total, w_off, (long long)(dsplit_off + dsplit[i]), c.cout, c.k * c.k, c.cin, 1});
+        t->sdesc_total += (long long)((c.cout + 31) & ~31) * c.k * c.k * c.cin;
+      }
+    }
+    t->sdesc_off = sdesc_off;
+    t->sdesc_uploaded = false;
     t->tab_off = tab_off;
     t->tabs_built = false;
     t->segs = segs;
@@ -331,9 +371,38 @@ int combine_sums(const TrainCtx& c, const ConvT& cv, int n_cols, double* count, 
   return 0;
 }
 
+// conv mode VY_CONV_SPLIT_BF16X3 in training: both sets of weight images follow the parameters (rebuilt after every
+// optimizer step: 0.6 GB of traffic, ~0.3 ms, beside a 26 ms step)
+int refresh_split_images(const TrainCtx& c) {
+  vy_net* net = c.net;
+  if (net->conv_mode != VY_CONV_SPLIT_BF16X3_TRAIN || !(net->split_dirty || net->dsplit_dirty) || c.t->sdesc.empty()) return 0;
+  SplitDesc* d = reinterpret_cast<SplitDesc*>(net->dev_ws + c.t->sdesc_off);
+  if (!c.t->sdesc_uploaded) {
+    HIP_TRY(hipMemcpyAsync(d, c.t->sdesc.data(), sizeof(SplitDesc) * c.t->sdesc.size(), hipMemcpyHostToDevice, c.s));
+    HIP_TRY(hipStreamSynchronize(c.s));  // pageable host vector; once per plan
+    c.t->sdesc_uploaded = true;
+  }
+  // one launch for every image set of the net (per-conv launches: 140 kernel boundaries per step)
+  HIP_TRY(vy_launch_split_weights_batch(net->dev_params, net->dev_ws, d, (int)c.t->sdesc.size(), c.t->sdesc_total, c.s));
+  net->split_dirty = net->dsplit_dirty = false;
+  return 0;
+}
+
+// the conv launch of the training passes: the split-fp32 kernel where the net's mode allows it, the launch has its
+// weight images (a.w_split) and the cost model predicts a gain; the exact kernel otherwise
+static int launch_conv(const ConvArgs& a, hipStream_t s) {
+  if (a.w_split && vy_conv_split_pays(a)) {
+    HIP_TRY(vy_launch_conv_split(a, s));
+  } else {
+    HIP_TRY(vy_launch_conv_igemm(a, s));
+  }
+  return 0;
+}
+
 int forward_train(const TrainCtx& c, const float* x) {
   vy_net* net = c.net;
   const int B = net->B;
+  if (int rc = refresh_split_images(c)) return rc;
   for (size_t ci = 0; ci < net->convs.size(); ++ci) {
     const ConvT& cv = net->convs[ci];
     if (cv.p_gamma < 0) {  // prediction conv: bias, no BN
@@ -370,9 +439,17 @@ int forward_train(const TrainCtx& c, const float* x) {
       a.o_s = 1;
       a.ups = 1;
       a.stats = reinterpret_cast<double*>(c.partials());
+      static const int train_split = getenv("VY_SPLIT_TRAIN") ? atoi(getenv("VY_SPLIT_TRAIN")) : 1;  // 0 none, 1 both, 2 forward only, 3 dgrad only
+      if (net->conv_mode != VY_CONV_SPLIT_BF16X3_TRAIN || train_split == 0 || train_split == 3) a.w_split = nullptr;
       if (!g_labels_done) g_labels.note("fwd", cv.name, a.M, a.N, (double)a.ntaps * a.Kc);
-      HIP_TRY(vy_launch_conv_igemm(a, c.s));
-      n_part = vy_conv_tiles_m(a);
+      if (int rc = launch_conv(a, c.s)) return rc;
+      if (a.w_split && vy_conv_split_pays(a)) {  // the per-tile statistics rows follow the tile that ran
+        int sbm, sbn, sks;
+        vy_conv_split_cfg(a, &sbm, &sbn, &sks);
+        n_part = (a.M + sbm - 1) / sbm;
+      } else {
+        n_part = vy_conv_tiles_m(a);
+      }
     }
     const int C = cv.cout;
     // statistics exchange between ranks only for the SyncBatchNorm layers; everywhere else the ordered
@@ -462,6 +539,15 @@ BwdDgrad make_dgrad(const TrainCtx& c, const ConvT& cv, const float* dzp, int dz
   a.ups = 1;
   a.dgrad = 1;
   net->set_sk(a);
+  {  // split-fp32 conv mode: this conv's data-gradient weight images and the split-K scratch (the stream-K region)
+    const size_t ci = (size_t)(&cv - net->convs.data());
+    static const int train_split = getenv("VY_SPLIT_TRAIN") ? atoi(getenv("VY_SPLIT_TRAIN")) : 1;
+    if (train_split != 2 && net->conv_mode == VY_CONV_SPLIT_BF16X3_TRAIN && ci < c.t->dsplit.size() && c.t->dsplit[ci] >= 0) {
+      a.w_split = net->dev_ws + c.t->dsplit_off + c.t->dsplit[ci];
+      a.splitk_slabs = reinterpret_cast<float*>(net->dev_ws + net->sk_off + vy_net::al((size_t)VY_SK_FLAGS * sizeof(unsigned)));
+      a.splitk_bytes = VY_SK_PARTIAL_BYTES;
+    }
+  }
   if (cv.stride == 1) {
     a.LH = ip.H;
     a.LW = ip.W;
@@ -729,7 +815,7 @@ int backward_train(const TrainCtx& c, const float* x) {
     const BwdDgrad dg = make_dgrad(c, cv, dzp, dz_cs, dzH, dzW, addend, add_cs, add_co);
     for (int k = 0; k < dg.n; ++k) {
       if (!g_labels_done) g_labels.note("dgrad", cv.name, dg.a[k].M, dg.a[k].N, (double)dg.a[k].ntaps * dg.a[k].Kc);
-      HIP_TRY(vy_launch_conv_igemm(dg.a[k], c.s));
+      if (int rc = launch_conv(dg.a[k], c.s)) return rc;
     }
     if (cov == 0) touched[cv.in_plane].push_back({lo, hi});
   }
@@ -777,6 +863,7 @@ int vy_net_bind_train(vy_net* net, void* dev_ws, size_t bytes, int32_t batch, in
   t->grads = static_cast<float*>(dev_grads);
   t->mom = static_cast<float*>(dev_momentum);
   t->forward_done = false;
+  t->sdesc_uploaded = false;  // (the workspace is zeroed below)
   hipStream_t s = static_cast<hipStream_t>(stream);
   HIP_TRY(hipMemsetAsync(dev_ws, 0, need, s));
   net->sk_dirty = false;
@@ -943,7 +1030,7 @@ int vy_net_sgd_step(vy_net* net, float lr, float momentum, float wd, float resca
   }
   HIP_TRY(vy_launch_sgd(net->dev_params, t->grads, t->mom, segs, chunks, (int)(t->chunk_seg.size() / 2), lr, momentum,
                         wd, rescale_grad, s));
-  net->split_dirty = true;  // conv mode VY_CONV_SPLIT_BF16X3: the weight images are stale now
+  net->split_dirty = net->dsplit_dirty = true;  // conv mode VY_CONV_SPLIT_BF16X3: the weight images are stale now
   return 0;
 }
 

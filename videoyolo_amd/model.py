@@ -435,8 +435,10 @@ class YOLOV3(object):
         algorithm itself).  ``'exact'`` (default): fp32 fma chains, bit-identical to the CPU checker — the parity
         path.  ``'split_bf16x3'``: opt-in, the 3x3 cells run on the bf16 matrix core with every fp32 operand cut
         exactly into three bf16 numbers (six partial products, fp32 accumulation; include/vyolo.h
-        ``vy_net_set_conv_mode``); training always uses the exact kernels."""
-        modes = {"exact": _lib.VY_CONV_EXACT_FP32, "split_bf16x3": _lib.VY_CONV_SPLIT_BF16X3}
+        ``vy_net_set_conv_mode``); training uses the exact kernels.  ``'split_bf16x3_train'`` (experimental): the
+        recorded forward and the data gradients of training on the split kernel too."""
+        modes = {"exact": _lib.VY_CONV_EXACT_FP32, "split_bf16x3": _lib.VY_CONV_SPLIT_BF16X3,
+                 "split_bf16x3_train": _lib.VY_CONV_SPLIT_BF16X3_TRAIN}
         if mode not in modes:
             raise ValueError("conv mode %r: expected one of %s" % (mode, sorted(modes)))
         _lib.check(self._lib.vy_net_set_conv_mode(self._h, modes[mode]))
@@ -777,7 +779,7 @@ class YOLOV3(object):
                 _lib.check(self._lib.vy_net_create(len(self._classes), ctypes.byref(th)))
                 _lib.check(self._lib.vy_net_bind_params(th, ctypes.c_void_p(self._dev_params.data_ptr())))
                 if getattr(self, "_conv_mode", "exact") != "exact":
-                    _lib.check(self._lib.vy_net_set_conv_mode(th, _lib.VY_CONV_SPLIT_BF16X3))
+                    _lib.check(self._lib.vy_net_set_conv_mode(th, _lib.VY_CONV_SPLIT_BF16X3))  # (inference only: the twin never trains)
                 # a stream of the library's own: torch's pooled streams may share the default stream's
                 # hardware queue, in which case the two launch sequences would simply alternate
                 sp = ctypes.c_void_p()
