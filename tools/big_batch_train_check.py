@@ -1,8 +1,8 @@
 """Training with activation planes of 4 GiB and more (round 4: the weight-gradient pixel table holds offsets relative to
-each split's first pixel; round 3 returned VY_ERR_UNSUPPORTED here).  608x608, batch 88: the stage-0 planes are
-88 x 610 x 610 x 32 x 4 B = 4.19 GB.  The batch is ONE frame repeated, so every batch statistic equals the single-frame
+each split's first pixel; round 3 returned VY_ERR_UNSUPPORTED here).  608x608, batch 92: the stage-0 planes are
+92 x 610 x 610 x 32 x 4 B = 4.38 GB = 4.08 GiB.  The batch is ONE frame repeated, so every batch statistic equals the single-frame
 statistic, every frame's forward / backward is the single-frame one, and the weight gradients (sums over the batch) must be
-88 x the single-frame gradients up to the fp32 summation order — an independent check that every pixel of a > 4 GiB plane is
+92 x the single-frame gradients up to the fp32 summation order — an independent check that every pixel of a > 4 GiB plane is
 addressed correctly.
 usage: python tools/big_batch_train_check.py [--batch 88] [--size 608]"""
 import argparse, os, sys
@@ -14,7 +14,7 @@ import videoyolo_amd as vy
 from videoyolo_amd import autograd, targets
 
 ap = argparse.ArgumentParser()
-ap.add_argument("--batch", type=int, default=88)
+ap.add_argument("--batch", type=int, default=92)
 ap.add_argument("--size", type=int, default=608)
 a = ap.parse_args()
 C = 20
