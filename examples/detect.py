@@ -2,7 +2,7 @@
 decoded uint8 frames of any size -> resize + to_tensor + normalise on the GPU -> net(x) -> clip / filter /
 normalise -> prediction lines, then VOC mAP against made-up ground truth.
 
-    python examples/detect.py [--size 608] [--batch 4] [--frames 8]
+    python examples/detect.py [--size 608] [--batch 4] [--frames 8] [--conv-mode split_bf16x3]
 """
 import argparse
 import os
@@ -20,6 +20,8 @@ def main():
     ap.add_argument("--size", type=int, default=608)
     ap.add_argument("--batch", type=int, default=4)
     ap.add_argument("--frames", type=int, default=8)
+    ap.add_argument("--conv-mode", default="exact", choices=["exact", "split_bf16x3"],
+                    help="exact: the parity path (default); split_bf16x3: the opt-in bf16 x 3 arithmetic (DESIGN.md 4.7)")
     args = ap.parse_args()
     classes = ["aeroplane", "bicycle", "bird", "boat", "bottle", "bus", "car", "cat", "chair", "cow", "diningtable",
                "dog", "horse", "motorbike", "person", "pottedplant", "sheep", "sofa", "train", "tvmonitor"]
@@ -27,6 +29,7 @@ def main():
     net.initialize(init="synthetic", seed=233, obj_bias=-4.0)   # no checkpoint offline: synthetic weights
     net.collect_params().reset_ctx("cuda:0")                    # :199
     net.set_nms(nms_thresh=0.45, nms_topk=400)                  # :200
+    net.set_conv_mode(args.conv_mode)                           # no counterpart in the reference (mxnet picks its conv algorithm)
     tf = transforms.YOLO3VideoInferenceTransform(args.size, args.size)
     metric = metrics.VOCMApMetric(iou_thresh=0.5, class_names=classes)
     rng = np.random.default_rng(0)

@@ -23,6 +23,14 @@ def test_detect_example():
     assert "3 frames" in out and "prediction lines" in out and "mAP" in out
 
 
+def test_detect_example_in_the_split_conv_mode():
+    exact = _run(["examples/detect.py", "--size", "416", "--batch", "2", "--frames", "3"])
+    split = _run(["examples/detect.py", "--size", "416", "--batch", "2", "--frames", "3", "--conv-mode", "split_bf16x3"])
+    assert "3 frames" in split and "mAP" in split
+    # the same detections survive (synthetic weights with a low objectness bias: a handful of boxes)
+    assert exact.split("prediction lines")[0] == split.split("prediction lines")[0]
+
+
 def test_train_example(tmp_path):
     out = _run(["examples/train.py", "--batch", "2", "--size", "96", "--steps", "3"])
     steps = [l for l in out.splitlines() if l.startswith("step ")]
