@@ -400,3 +400,40 @@ def test_split_training_equals_exact_training_when_switched_off(voc_classes, syn
     lc, gc = step(b)
     assert all(np.array_equal(u, v) for u, v in zip(la, lc)) and np.array_equal(ga, gc)
     assert not np.array_equal(ga, gb)       # the split step really was a different summation
+
+
+@pytest.mark.parametrize("ncls,batch,obj_bias", [(20, 64, 0.0), (30, 32, -4.0)])
+def test_split_inference_full_size(ncls, batch, obj_bias, monkeypatch, capsys):
+    """BASELINE configs[1] / configs[3] shapes (608 x 608, batch 64 / 30 classes batch 32) in the split conv mode under the
+    PRODUCT's policy (no VY_SPLIT_ALWAYS): run-to-run bit-reproducible, frame order does not matter, box_nms invariants on
+    every frame, and two frames against the oracle — heads within HEAD_TOL, kept rows up to near-ties."""
+    import torch
+    from videoyolo_amd import init
+    from oracle import yolo3_oracle as O
+    from test_gpu_fullsize import _check_nms_invariants
+    monkeypatch.delenv("VY_SPLIT_ALWAYS")
+    classes = ["c%d" % i for i in range(ncls)]
+    params = init.synthetic_params(O.param_shapes(ncls), seed=233, obj_bias=obj_bias)
+    net = _net(classes, params)
+    x = torch.as_tensor(frames(batch, 608, seed=7)).cuda()
+    names = _split_launches(net, x)
+    assert sum("|split" in n for n in names) >= 67   # (a marginal 1x1 launch may stay on the exact kernel: the model decides)
+    out = [t.clone() for t in net(x, return_index=True)]
+    again = net(x, return_index=True)
+    assert all(torch.equal(a, b) for a, b in zip(out, again)), "not reproducible run to run"
+    heads = [net.read_head(i).cpu().numpy() for i in range(3)]   # (of the forward just run: before the reversed batch)
+    perm = torch.arange(batch - 1, -1, -1, device=x.device)
+    rev = net(x[perm].contiguous(), return_index=True)
+    assert all(torch.equal(a[perm], b) for a, b in zip(out, rev)), "frame order changes the results"
+    ids, scores, bboxes, keep = [t.cpu().numpy() for t in out]
+    _check_nms_invariants(ids, scores, bboxes, ncls, 0.45, 100)
+    orc = O.OracleYolo3(ncls, params)
+    for j in (0, batch - 1):
+        xj = x[j:j + 1].cpu().numpy()
+        ref = orc.raw_heads(xj)
+        worst = max(float(np.abs(heads[i][j:j + 1] - ref[i]).max()) for i in range(3))
+        assert worst <= HEAD_TOL, (j, worst)
+        r = orc(xj)
+        exc = _check_keep(keep[j:j + 1], r[3], orc.detections(xj), "608 batch %d frame %d" % (batch, j), capsys)
+        assert len(exc) <= 4
+        np.testing.assert_allclose(np.sort(scores[j:j + 1], 1), np.sort(r[1], 1), rtol=0, atol=TOL)
