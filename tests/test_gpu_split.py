@@ -346,11 +346,15 @@ def test_split_training_step_within_the_steps_own_sensitivity(C, B, S, capsys):
     assert d_split < 0.1
 
 
-def test_split_data_gradients_alone_meet_the_exact_bars():
-    """VY_SPLIT_TRAIN=3 (own process: the switch is read once): forward EXACT — bit-equal to the oracle, so no branch
-    flips — and the data gradients on the split kernel (its [k = cout][n = cin] weight images, flipped taps, the four
-    parity classes of the stride-2 convs, cout = 3 (5 + C) zero-padded to 32 for the prediction convs, accumulate into
-    a skip gradient).  Then the exact path's own bars hold: losses 1e-4, every gradient within 2e-3 of its tensor's max."""
+@pytest.mark.parametrize("which,env", [("data gradients", {"VY_SPLIT_TRAIN": "3", "VY_SPLIT_WGRAD": "0"}),
+                                       ("weight gradients", {"VY_SPLIT_TRAIN": "0", "VY_SPLIT_WGRAD": "1"})])
+def test_split_gradients_alone_meet_the_exact_bars(which, env):
+    """Own process (the switches are read once): forward EXACT — bit-equal to the oracle, so no branch flips — and ONE
+    kind of gradient on its split kernel.  VY_SPLIT_TRAIN=3: the data gradients (conv_split.hip: [k = cout][n = cin] weight
+    images, flipped taps, the four parity classes of the stride-2 convs, cout = 3 (5 + C) zero-padded to 32 for the
+    prediction convs, accumulate into a skip gradient).  VY_SPLIT_WGRAD=1 with VY_SPLIT_TRAIN=0: the weight gradients
+    (wgrad_split.hip: both operands split in registers, transposed LDS reads, split-K slabs) of every conv with
+    cout % 128 == 0.  Then the exact path's own bars hold: losses 1e-4, every gradient within 2e-3 of its tensor's max."""
     import subprocess
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
@@ -367,12 +371,12 @@ def test_split_data_gradients_alone_meet_the_exact_bars():
         "    assert all(np.allclose(a, b, rtol=1e-4, atol=1e-4) for a, b in zip(l, rl))\n"
         "    worst = max(worst, max(float(np.abs(g[k] - rg[k]).max() / (np.abs(rg[k]).max() + 1e-6)) for k in rg))\n"
         "print('RESULT', json.dumps({'worst': worst}))\n") % (here, os.path.dirname(here))
-    env = dict(os.environ, VY_SPLIT_TRAIN="3", VY_SPLIT_ALWAYS="1")
+    env = dict(os.environ, VY_SPLIT_ALWAYS="1", **env)
     p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stderr[-3000:]
     import json
     r = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("RESULT ")][-1][7:])
-    assert r["worst"] < 2e-3, r
+    assert r["worst"] < 2e-3, (which, r)
 
 
 def test_split_training_equals_exact_training_when_switched_off(voc_classes, synth20, monkeypatch):

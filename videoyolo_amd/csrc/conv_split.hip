@@ -146,14 +146,13 @@ hipError_t vy_launch_split_weights_dgrad(const float* w, void* img, int cout, in
 }
 
 // Every conv's images in ONE launch (the per-conv launches above cost 70 x 2 kernel boundaries per training step):
-// descriptors sorted by `first` (prefix sum of the element counts); a thread finds its conv by bisection.
+// descriptors sorted by `first` (prefix sum of the OCTET counts); a thread finds its conv by bisection and converts one
+// 8-channel octet: 32 B in (forward images: contiguous; data-gradient images: 8 output channels at one (tap, cin), each
+// read coalesced across the threads of a wave, which differ in cin), three 16-B stores out.
 __global__ __launch_bounds__(256) void split_weights_batch_kernel(const float* __restrict__ params, unsigned char* __restrict__ ws,
                                                                   const SplitDesc* __restrict__ d, const int n,
                                                                   const long long total) {
-  auto rne = [](float f) -> unsigned {
-    const unsigned u = __builtin_bit_cast(unsigned, f);
-    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
-  };
+#if defined(__HIP_DEVICE_COMPILE__)
   for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long long)gridDim.x * blockDim.x) {
     int lo = 0, hi = n - 1;
     while (lo < hi) {
@@ -162,32 +161,65 @@ __global__ __launch_bounds__(256) void split_weights_batch_kernel(const float* _
       else hi = mid - 1;
     }
     const SplitDesc c = d[lo];
-    const long long e = g - c.first;
+    const long long e = g - c.first;  // octet index inside this image set
     const int cin = c.cin, taps = c.taps;
-    const int ci = (int)(e % cin);
-    const long long t_ = e / cin;
-    const int tap = (int)(t_ % taps), o = (int)(t_ / taps);
-    const float x = o < c.cout ? params[c.w_off + e] : 0.0f;
-    const unsigned h = rne(x);
-    const float r = x - __builtin_bit_cast(float, h << 16);
-    const unsigned m = rne(r);
-    const float q = r - __builtin_bit_cast(float, m << 16);
-    const unsigned l = rne(q);
-    unsigned short* img = reinterpret_cast<unsigned short*>(ws + c.img_off);
+    float x[8];
     long long base;
-    if (!c.dgrad) {
+    if (!c.dgrad) {  // octet = 8 consecutive input channels of (o, tap)
+      const int co = cin >> 3;
+      const int oc = (int)(e % co);
+      const long long t_ = e / co;
+      const int tap = (int)(t_ % taps), o = (int)(t_ / taps);
+      const f32x4* src = reinterpret_cast<const f32x4*>(params + c.w_off + ((long long)o * taps + tap) * cin + oc * 8);
+      const f32x4 v0 = src[0], v1 = src[1];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        x[j] = v0[j];
+        x[4 + j] = v1[j];
+      }
       const int KS = taps * (cin >> 4);
-      const int ng = o >> 5, row = o & 31, ks = tap * (cin >> 4) + (ci >> 4), oct = (ci >> 3) & 1, j = ci & 7;
-      base = (((long long)ng * KS + ks) * 3) * 512 + row * 16 + (VY_SPLIT_SLOT(row, oct) << 3) + j;
-    } else {
-      const int coutp = (c.cout + 31) & ~31, KS = taps * (coutp >> 4);
-      const int ng = ci >> 5, row = ci & 31, ks = tap * (coutp >> 4) + (o >> 4), oct = (o >> 3) & 1, j = o & 7;
-      base = (((long long)ng * KS + ks) * 3) * 512 + row * 16 + (VY_SPLIT_SLOT(row, oct) << 3) + j;
+      const int ng = o >> 5, row = o & 31, ks = tap * (cin >> 4) + (oc >> 1), oct = oc & 1;
+      base = (((long long)ng * KS + ks) * 3) * 1024 + row * 32 + (VY_SPLIT_SLOT(row, oct) << 4);
+    } else {  // octet = 8 consecutive output channels at (tap, cin); cout zero-padded to a multiple of 32
+      const int coutp = (c.cout + 31) & ~31;
+      const int ci = (int)(e % cin);
+      const long long t_ = e / cin;
+      const int tap = (int)(t_ % taps), oo = (int)(t_ / taps);  // output-channel octet
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int o = oo * 8 + j;
+        x[j] = o < c.cout ? params[c.w_off + ((long long)o * taps + tap) * cin + ci] : 0.0f;
+      }
+      const int KS = taps * (coutp >> 4);
+      const int ng = ci >> 5, row = ci & 31, ks = tap * (coutp >> 4) + (oo >> 1), oct = oo & 1;
+      base = (((long long)ng * KS + ks) * 3) * 1024 + row * 32 + (VY_SPLIT_SLOT(row, oct) << 4);
     }
-    img[base] = (unsigned short)h;
-    img[base + 512] = (unsigned short)m;
-    img[base + 1024] = (unsigned short)l;
+    auto rne = [](float f) -> unsigned {
+      const unsigned u = __builtin_bit_cast(unsigned, f);
+      return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+    };
+    vy_u32x4 H, M, L;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      unsigned hh[2], mm[2], ll[2];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const float v = x[2 * j + q];
+        hh[q] = rne(v);
+        const float r = v - __builtin_bit_cast(float, hh[q] << 16);
+        mm[q] = rne(r);
+        ll[q] = rne(r - __builtin_bit_cast(float, mm[q] << 16));
+      }
+      H[j] = hh[0] | (hh[1] << 16);
+      M[j] = mm[0] | (mm[1] << 16);
+      L[j] = ll[0] | (ll[1] << 16);
+    }
+    unsigned char* img = ws + c.img_off + base;  // byte offset: image (ng, ks, plane) = 1 KiB, row 32 B, slot 16 B
+    *reinterpret_cast<vy_u32x4*>(img) = H;
+    *reinterpret_cast<vy_u32x4*>(img + 1024) = M;
+    *reinterpret_cast<vy_u32x4*>(img + 2048) = L;
   }
+#endif
 }
 
 hipError_t vy_launch_split_weights_batch(const float* params, void* ws, const SplitDesc* descs_dev, int n, long long total,

@@ -83,9 +83,10 @@ hipError_t vy_launch_split_weights(const float* w, void* img, int cout, int taps
 size_t vy_split_weight_dgrad_bytes(int cout, int taps, int cin);
 hipError_t vy_launch_split_weights_dgrad(const float* w, void* img, int cout, int taps, int cin, hipStream_t s);
 // all images of a net in one launch: descriptors (device memory, sorted by `first`) of `n` image sets covering `total`
-// weight elements (dgrad sets count their zero-padded cout); params / ws: the parameter buffer and the workspace
+// 8-channel OCTETS (a thread converts one; dgrad sets count their zero-padded cout); params / ws: the parameter buffer
+// and the workspace
 struct SplitDesc {
-  long long first;     // index of this set's first element in the launch's flat element range
+  long long first;     // index of this set's first octet in the launch's flat octet range
   long long w_off;     // element offset of the conv's weights in the parameter buffer
   long long img_off;   // byte offset of the images in the workspace
   int cout, taps, cin, dgrad;
@@ -249,6 +250,10 @@ struct WgradArgs {
   int xcd_order;          // filled by the launcher: XCD-contiguous (split, tile) order (wgrad.hip)
 };
 hipError_t vy_launch_wgrad(const WgradArgs& a, hipStream_t s);
+// EXPERIMENTAL split-fp32 weight gradient (wgrad_split.hip: bf16 x 3, six products; same WgradArgs, table and slabs):
+// Cout % 128 == 0
+bool vy_wgrad_split_supported(const WgradArgs& a);
+hipError_t vy_launch_wgrad_split(const WgradArgs& a, hipStream_t s);
 // output rows (dz channels) of a weight-gradient block tile: 64 or 128 (the planner's split count depends on it)
 int vy_wgrad_tile_rows(int Cout, int k, int Cin);
 // per-pixel byte offsets (dz vector, input-plane centre pixel shifted by one row + one column) for vy_launch_wgrad,

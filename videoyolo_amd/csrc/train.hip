@@ -316,11 +316,11 @@ size_t train_plan(vy_net* net, int b, int h, int w, bool commit) {
       const long long w_off = net->params[c.p_weight].info.offset;
       if (c.split_off >= 0) {
         t->sdesc.push_back(SplitDesc{t->sdesc_total, w_off, (long long)(net->wsplit_off + c.split_off), c.cout, c.k * c.k, c.cin, 0});
-        t->sdesc_total += (long long)c.cout * c.k * c.k * c.cin;
+        t->sdesc_total += (long long)c.cout * c.k * c.k * c.cin / 8;
       }
       if (dsplit[i] >= 0) {
         t->sdesc.push_back(SplitDesc{t->sdesc_total, w_off, (long long)(dsplit_off + dsplit[i]), c.cout, c.k * c.k, c.cin, 1});
-        t->sdesc_total += (long long)((c.cout + 31) & ~31) * c.k * c.k * c.cin;
+        t->sdesc_total += (long long)((c.cout + 31) & ~31) * c.k * c.k * c.cin / 8;
       }
     }
     t->sdesc_off = sdesc_off;
@@ -616,7 +616,13 @@ int launch_wgrad(const TrainCtx& c, size_t ci, const float* dzp, int dz_cs, int 
   w.k_per_split = c.t->kps[ci];
   w.tab = reinterpret_cast<const uint2*>(net->dev_ws + c.t->tab_off[ci]);
   if (!g_labels_done) g_labels.note("wgrad", cv.name, w.M, w.Cout, (double)cv.k * cv.k * cv.cin);
-  HIP_TRY(vy_launch_wgrad(w, ws));
+  // conv mode VY_CONV_SPLIT_BF16X3_TRAIN: the split-fp32 weight-gradient kernel where it has the tile (Cout % 128 == 0)
+  static const int wgrad_split = getenv("VY_SPLIT_WGRAD") ? atoi(getenv("VY_SPLIT_WGRAD")) : 1;
+  if (wgrad_split && net->conv_mode == VY_CONV_SPLIT_BF16X3_TRAIN && vy_wgrad_split_supported(w)) {
+    HIP_TRY(vy_launch_wgrad_split(w, ws));
+  } else {
+    HIP_TRY(vy_launch_wgrad(w, ws));
+  }
   HIP_TRY(vy_launch_slab_reduce(c.slabs(), w.splits, (long long)cv.cout * cv.k * cv.k * cv.cin,
                                 c.grad_of(cv.p_weight), ws));
   return 0;
