@@ -21,8 +21,8 @@ Prints ONE JSON line on rank 0 (contract in the task statement) with extra objec
                   products, fp32 accumulate — NOT the parity path; tolerances in tests/test_gpu_split.py): frames/s,
                   conv rate against the fp32 roof and against the bf16 roof / 6, batch-1 latency, HBM traffic.
                   The headline `value` stays the exact-fp32 path.
-  also_train416_split  (--train-split-leg only) BASELINE configs[2] with the recorded forward and the data gradients in
-                  conv mode split_bf16x3_train (weight gradients exact)
+  also_train416_split  BASELINE configs[2] in conv mode split_bf16x3_train (recorded forward, data gradients and weight
+                  gradients on the bf16 matrix core); separately reported, like also_infer608_split
   also_train416   BASELINE configs[2] at the same N: training step 416x416, 16 frames per GPU (recorded forward +
                   backward + gradient all-reduce over RCCL, bucketed and overlapped + SGD), timed the same way
                   (barrier + synchronize, max over ranks) — with the forward / backward / exposed-all-reduce split,
@@ -404,9 +404,6 @@ def main():
                     help="arithmetic of the HEADLINE inference step (default exact fp32: the parity path); the default "
                          "line reports the split mode beside it as also_infer608_split")
     ap.add_argument("--no-split-leg", action="store_true", help="skip also_infer608_split")
-    ap.add_argument("--train-split-leg", action="store_true",
-                    help="add also_train416_split: the training step in conv mode split_bf16x3_train (experimental: measured "
-                         "no faster than the exact step, which is bound by the weight gradients)")
     ap.add_argument("--no-train-legs", action="store_true",
                     help="infer mode: skip also_train416 / also_syncbn608 (BASELINE configs[2] / [4])")
     ap.add_argument("--train-steps", type=int, default=10, help="timed steps of each training leg")
@@ -701,12 +698,13 @@ def main():
             leg["traffic"] = None
             leg["traffic_note"] = train_traffic_note
         result["also_train416"] = leg
-        if args.train_split_leg:
-            # the same training step with forward + data gradients in the split-fp32 conv mode (experimental; slower)
+        if not args.no_split_leg:
+            # the same training step in conv mode split_bf16x3_train (forward, data and weight gradients on the bf16 matrix
+            # core; NOT the parity path): separately reported, like also_infer608_split
             sleg = train_leg(vy, dev, dist, rank, world, args.train_size, args.train_batch, args.classes,
                              args.train_steps, args.warmup, syncbn=False, overlap=True, allreduce_alone=False,
                              conv_mode="split_bf16x3_train")
-            sleg["dtype"] = SPLIT_DTYPE + " (recorded forward and data gradients; weight gradients exact f32)"
+            sleg["dtype"] = SPLIT_DTYPE + " (recorded forward, data gradients, weight gradients of the convs with cout % 128 == 0)"
             sleg["speedup_over_exact"] = sleg["frames_per_s"] / leg["frames_per_s"]
             sleg["workload"] = leg["workload"] + "; net.set_conv_mode('split_bf16x3')"
             result["also_train%d_split" % args.train_size] = sleg

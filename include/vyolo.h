@@ -127,9 +127,11 @@ int vy_net_set_keep_activations(vy_net* net, int32_t keep);
  *                          (csrc/conv_split.hip); NOT bit-equal to the exact path (tolerances:
  *                          tests/test_gpu_split.py), 1.3x the frames/s at 608x608 batch 64.  Planes, stem, prediction
  *                          convs, decode and NMS are shared with the exact path.  Training runs the exact kernels.
- *   VY_CONV_SPLIT_BF16X3_TRAIN   as above, and the recorded forward and the data gradients of TRAINING too (weight
- *                          gradients stay exact).  Experimental: correct (same tests), but no faster at 416x416 batch 16 —
- *                          the step is bound by the weight gradients.
+ *   VY_CONV_SPLIT_BF16X3_TRAIN   as above, and TRAINING too: the recorded forward, the data gradients (conv_split.hip)
+ *                          and the weight gradients of every conv with cout % 128 == 0 (wgrad_split.hip) on the bf16
+ *                          matrix core; 1.13x the training frames/s at 416x416 batch 16.  Losses within 1e-4 of the exact
+ *                          path; gradients as far from it as a one-ulp change of the input moves the exact path's own
+ *                          (tests/test_gpu_split.py).
  * Changes the plan (the pre-split weight images live in the workspace): call before vy_net_workspace_bytes /
  * vy_net_bind_workspace; a bound workspace is unbound by a change. */
 enum vy_conv_mode { VY_CONV_EXACT_FP32 = 0, VY_CONV_SPLIT_BF16X3 = 1, VY_CONV_SPLIT_BF16X3_TRAIN = 2 };

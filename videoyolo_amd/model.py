@@ -435,8 +435,8 @@ class YOLOV3(object):
         algorithm itself).  ``'exact'`` (default): fp32 fma chains, bit-identical to the CPU checker — the parity
         path.  ``'split_bf16x3'``: opt-in, the 3x3 cells run on the bf16 matrix core with every fp32 operand cut
         exactly into three bf16 numbers (six partial products, fp32 accumulation; include/vyolo.h
-        ``vy_net_set_conv_mode``); training uses the exact kernels.  ``'split_bf16x3_train'`` (experimental): the
-        recorded forward and the data gradients of training on the split kernel too."""
+        ``vy_net_set_conv_mode``); training uses the exact kernels.  ``'split_bf16x3_train'``: training too — the
+        recorded forward, the data gradients and the weight gradients (cout % 128 == 0) on the split kernels."""
         modes = {"exact": _lib.VY_CONV_EXACT_FP32, "split_bf16x3": _lib.VY_CONV_SPLIT_BF16X3,
                  "split_bf16x3_train": _lib.VY_CONV_SPLIT_BF16X3_TRAIN}
         if mode not in modes:
