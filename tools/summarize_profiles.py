@@ -35,6 +35,9 @@ for src, dst in [("%s_infer608_b64_bench.json", "%s_infer608_b64_bench.json"),
                  ("%s_layers_608_b64_split.txt", "%s_layers_608_b64_split.txt"),
                  ("%s_infer608_b64_split_bench_under_rocprof.json", "%s_infer608_b64_split_bench_under_rocprof.json"),
                  ("%s_small_batch_latency.txt", "%s_small_batch_latency.txt"),
+                 ("%s_layers_608_b1.txt", "%s_layers_608_b1.txt"),
+                 ("%s_layers_608_b1_split.txt", "%s_layers_608_b1_split.txt"),
+                 ("%s_ab_split_train.txt", "%s_ab_split_train.txt"),
                  ("%s_small_batch_latency_split.txt", "%s_small_batch_latency_split.txt"),
                  ("%s_layers.txt", "%s_train416_b16_layers.txt")]:
     if os.path.exists(os.path.join(G, src % tag)):
