@@ -242,12 +242,7 @@ hipError_t vy_launch_split_weights(const float* w, void* img, int cout, int taps
 
 // NSA = LDS stages of the A tile (written one k-step ahead: two suffice; three where they fit let the loop unroll by 3
 // instead of 6); the W tile has three (its DMA is issued two k-steps ahead).
-// DEEP: the instance for launches that leave a CU with ONE block (a single frame's layers, split-K slices): nobody else
-// covers the block's load latency, and with loads issued one k-step ahead the k-loop ran at the latency of an L2 round trip
-// per k-step (0.66 us for 0.32 us of matrix work).  DEEP issues the A loads and the W DMA THREE k-steps ahead (two
-// register sets for A, four LDS stages each), all loads as inline asm so that the waits can be counted by hand:
-// `s_waitcnt vmcnt(ops of one k-step)` — everything but the youngest k-step's loads — once per k-step.
-template <int BM, int BN, int NSA, bool DEEP = false>
+template <int BM, int BN, int NSA>
 // ksplit > 1: split-K for launches of few tiles (a single frame's deep layers): block (tile, s) runs k-steps
 // [s T / ksplit, (s + 1) T / ksplit) and stores its raw accumulators to slab s of a.splitk_slabs ([ksplit][M][N] fp32);
 // splitk_finish_kernel adds the slabs in order and applies the epilogue.  (The exact kernel cannot do this — its fma
@@ -256,15 +251,14 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(const ConvArgs a, co
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int WM = 2, WN = 2, NW = 4, NT = 256;
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-  constexpr int NSW = DEEP ? 4 : 3;
+  constexpr int NSW = 3;
   constexpr int A_PL = BM * 32, W_PL = BN * 32;          // bytes of one plane of a stage (rows x 32 B)
   constexpr int A_ST = 3 * A_PL, W_ST = 3 * W_PL;
   constexpr int W_BASE = NSA * A_ST;                     // LDS: [A stages][W stages][row tables]
   constexpr int W_TOTAL = (BN / 32) * 3;                 // LDS-DMA instructions per block per k-step ...
   constexpr int W_INSTR = (W_TOTAL + NW - 1) / NW;       // ... and per wave (the last ones only on some waves)
   constexpr int A_SETS = BM * 2 / NT;                    // (row, octet) pairs per thread per k-step
-  static_assert(A_SETS >= 1 && TM >= 1 && TN >= 1 && (NSA == 2 || NSA == 3 || (DEEP && NSA == 4)), "tile");
-  static_assert(!DEEP || A_SETS == 1, "the deep instance keeps two register sets of ONE (row, octet) pair per thread");
+  static_assert(A_SETS >= 1 && TM >= 1 && TN >= 1 && (NSA == 2 || NSA == 3), "tile");
   __shared__ __attribute__((aligned(16))) unsigned char smem[NSA * A_ST + NSW * W_ST + BM * 16];
   long long* in_off = reinterpret_cast<long long*>(smem + NSA * A_ST + NSW * W_ST);
   unsigned* o_off = reinterpret_cast<unsigned*>(in_off + BM);
@@ -461,10 +455,9 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(const ConvArgs a, co
   using S0 = std::integral_constant<int, 0>;
   using S1 = std::integral_constant<int, 1>;
   using S2 = std::integral_constant<int, 2>;
-  using S3 = std::integral_constant<int, 3>;
   using Y = std::true_type;
   using N_ = std::false_type;
-  if constexpr (!DEEP) {
+  {
     // one k-step on W stage `stw` / A stage `sta` (std::integral_constant in the unrolled main loop, so that the stage
     // offsets fold into the ds_read / ds_write immediates; plain ints in the tail)
     auto kstep = [&](auto stw_, auto sta_, auto has1_, auto has2_) {
@@ -515,76 +508,6 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(const ConvArgs a, co
       if (after >= 2) kstep(stw, sta, Y{}, Y{});
       else if (after == 1) kstep(stw, sta, Y{}, N_{});
       else kstep(stw, sta, N_{}, N_{});
-    }
-  } else {
-    // ---- deep pipeline.  Per k-step every wave issues the same number of vector-memory operations, in this order:
-    // 2 A loads, W_INSTR DMA (waves without a real last DMA re-issue their first one: a duplicate 1-KiB copy keeps
-    // the counts equal) — so `vmcnt(OPS)` means "everything except the youngest k-step's loads has arrived".
-    constexpr int OPS = 2 + W_INSTR;
-    f32x4 ar[2][2];  // register set (k-step parity) x the two 16-byte halves of the thread's 8 channels
-    auto issue = [&](auto set_, int stage) {  // k-step's loads: A -> register set, W -> LDS stage
-      constexpr int SET = decltype(set_)::value;
-      advance();
-      const float* pa = a_ptr[0] + a_koff;
-      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(ar[SET][0]) : "v"(pa) : "memory");
-      asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(ar[SET][1]) : "v"(pa) : "memory");
-#pragma unroll
-      for (int j = 0; j < W_INSTR; ++j) {
-        const int jj = (W_TOTAL % NW == 0 || j * NW + wave < W_TOTAL) ? j : 0;
-        lds_dma16_s(w_voff[jj], reinterpret_cast<const float*>(w_tile + w_koff), lds0 + W_BASE + stage * W_ST + (w_lds[jj] - W_BASE));
-      }
-    };
-    auto convert = [&](auto set_, auto pending_, int stage) {  // wait for the set's loads, split, store to the A stage
-      constexpr int SET = decltype(set_)::value;
-      constexpr int PENDING = decltype(pending_)::value;  // vector-memory operations issued after this set's k-step
-      asm volatile("s_waitcnt vmcnt(%2)" : "+v"(ar[SET][0]), "+v"(ar[SET][1]) : "n"(PENDING) : "memory");
-      vy_u32x4 H, M, L;
-      split8(ar[SET][0], ar[SET][1], H, M, L);
-      unsigned char* d = smem + stage * A_ST + a_lds[0];
-      *reinterpret_cast<vy_u32x4*>(d) = H;
-      *reinterpret_cast<vy_u32x4*>(d + A_PL) = M;
-      *reinterpret_cast<vy_u32x4*>(d + 2 * A_PL) = L;
-    };
-    using P0 = std::integral_constant<int, 0>;
-    using P1 = std::integral_constant<int, 1>;
-    using W1 = std::integral_constant<int, OPS>;
-    using W0 = std::integral_constant<int, 0>;
-    // k-step t (stage t % 4): convert k-step t+1 (register set (t+1) & 1, loaded two k-steps ago), then re-use that set for
-    // k-step t+3.  `more2`: k-step t+2 exists (its loads are the youngest in flight at the wait); `more3`: t+3 exists.
-    auto kstep = [&](int st, auto set1_, auto more2_, auto more3_, bool has1) {
-      constexpr bool MORE2 = decltype(more2_)::value, MORE3 = decltype(more3_)::value;
-      lds_barrier();
-      if (has1) {
-        if constexpr (MORE2) convert(set1_, W1{}, (st + 1) & 3);
-        else convert(set1_, W0{}, (st + 1) & 3);
-      }
-      if constexpr (MORE3) issue(set1_, (st + 3) & 3);
-      compute(smem + st * A_ST, smem + st * W_ST);
-    };
-    // prologue: k-steps 0, 1 (and 2) in flight; k-step 0 converted
-    issue(P0{}, 0);
-    if (T > 1) issue(P1{}, 1);
-    if (T > 1) convert(P0{}, W1{}, 0);
-    else convert(P0{}, W0{}, 0);
-    if (T > 2) issue(P0{}, 2);
-    int t = 0;
-    for (; t + 4 <= T - 3; t += 4) {  // t+3 .. t+6 exist
-      kstep(0, P1{}, Y{}, Y{}, true);
-      kstep(1, P0{}, Y{}, Y{}, true);
-      kstep(2, P1{}, Y{}, Y{}, true);
-      kstep(3, P0{}, Y{}, Y{}, true);
-    }
-    for (; t < T; ++t) {
-      const int after = T - 1 - t, st = t & 3;
-      if ((t + 1) & 1) {
-        if (after >= 3) kstep(st, P1{}, Y{}, Y{}, true);
-        else if (after == 2) kstep(st, P1{}, Y{}, N_{}, true);
-        else kstep(st, P1{}, N_{}, N_{}, after == 1);
-      } else {
-        if (after >= 3) kstep(st, P0{}, Y{}, Y{}, true);
-        else if (after == 2) kstep(st, P0{}, Y{}, N_{}, true);
-        else kstep(st, P0{}, N_{}, N_{}, after == 1);
-      }
     }
   }
 
@@ -820,10 +743,10 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(const ConvArgs a, co
   }
 }
 
-template <int BM, int BN, int NSA, bool DEEP = false>
+template <int BM, int BN, int NSA>
 static hipError_t launch_split(const ConvArgs& a, int ksplit, hipStream_t s) {
   const int tiles_m = (a.M + BM - 1) / BM, tiles_n = a.N / BN;
-  hipLaunchKernelGGL((conv_split_kernel<BM, BN, NSA, DEEP>), dim3(tiles_m * tiles_n * ksplit), dim3(256), 0, s, a, tiles_n, ksplit);
+  hipLaunchKernelGGL((conv_split_kernel<BM, BN, NSA>), dim3(tiles_m * tiles_n * ksplit), dim3(256), 0, s, a, tiles_n, ksplit);
   if (ksplit > 1) {
     const long long work = (long long)a.M * (a.N >> 2);
     hipLaunchKernelGGL(splitk_finish_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, s, a, ksplit);
@@ -846,15 +769,11 @@ hipError_t vy_launch_conv_split(const ConvArgs& a_in, hipStream_t s) {
   }
   int bm, bn, ks;
   vy_conv_split_cfg(a, &bm, &bn, &ks);
-  // The deep-pipeline instance (loads three k-steps ahead) was built for launches that leave a CU with one block and
-  // measured NO faster than the plain one on any single-frame layer (19x19 K = 4608 as 10 slices: 33.4 vs 32.5 us, 38x38:
-  // 34.0 vs 33.3, 1x1 layers 1-5 % slower; profiles/r04_negative_results.txt section 3): those launches are bound by
-  // their fixed parts (two launches, prologue, slab round trip), not by load latency.  OFF; VY_SPLIT_DEEP=1 for experiments.
-  static const int deep_sw = getenv("VY_SPLIT_DEEP") ? atoi(getenv("VY_SPLIT_DEEP")) : 0;
-  const long long blocks = (long long)((a.M + bm - 1) / bm) * (a.N / bn) * ks;
-  const bool deep = deep_sw != 0 && blocks <= (bn == 128 ? 256 : 512);
-  if (bm == 128 && bn == 128) return deep ? launch_split<128, 128, 4, true>(a, ks, s) : launch_split<128, 128, 3>(a, ks, s);
+  // (Two more instances were built, measured on the MI355X and removed — profiles/r04_negative_results.txt sections 3 and
+  // 7: a deep pipeline for launches that leave a CU with one block, loads three k-steps ahead: no gain; the A operand
+  // pre-split into bf16 planes and DMA'd like the weights: 3.5-14 % slower.)
+  if (bm == 128 && bn == 128) return launch_split<128, 128, 3>(a, ks, s);
   if (bm == 256 && bn == 64) return launch_split<256, 64, 2>(a, ks, s);
-  if (bm == 128 && bn == 64) return deep ? launch_split<128, 64, 4, true>(a, ks, s) : launch_split<128, 64, 3>(a, ks, s);
+  if (bm == 128 && bn == 64) return launch_split<128, 64, 3>(a, ks, s);
   return hipErrorInvalidValue;
 }
