@@ -250,7 +250,7 @@ struct WgradArgs {
   int xcd_order;          // filled by the launcher: XCD-contiguous (split, tile) order (wgrad.hip)
 };
 hipError_t vy_launch_wgrad(const WgradArgs& a, hipStream_t s);
-// EXPERIMENTAL split-fp32 weight gradient (wgrad_split.hip: bf16 x 3, six products; same WgradArgs, table and slabs):
+// opt-in split-fp32 weight gradient (wgrad_split.hip: bf16 x 3, six products; same WgradArgs, table and slabs):
 // Cout % 128 == 0
 bool vy_wgrad_split_supported(const WgradArgs& a);
 hipError_t vy_launch_wgrad_split(const WgradArgs& a, hipStream_t s);

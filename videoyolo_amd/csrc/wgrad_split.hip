@@ -1,4 +1,4 @@
-// wgrad_split.hip — EXPERIMENTAL split-fp32 weight gradient on the bf16 matrix core (conv mode
+// wgrad_split.hip — OPT-IN split-fp32 weight gradient on the bf16 matrix core (conv mode
 // VY_CONV_SPLIT_BF16X3_TRAIN): the same arithmetic as conv_split.hip (every fp32 operand cut exactly into three bf16
 // numbers, six partial products per multiply, fp32 accumulate), for the reduction the training step is bound by
 // (wgrad.hip: 17.6 ms of kernel time per 30.4 ms step at 416x416, batch 16).  Not the parity path.
