@@ -207,6 +207,30 @@ def test_bench_starts_its_own_ranks(extra):
         assert r["step_split"]["forward_ms"] > 0 and "allreduce_exposed_ms" in r["step_split"]   # (roofline: 416 / 608 only)
 
 
+def test_bench_under_torch_distributed_run():
+    """The driver's own command for N > 1: `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr
+    127.0.0.1 --master-port P bench.py --gpus N ...` — bench.py finds RANK / LOCAL_RANK / WORLD_SIZE in the environment,
+    does not spawn, and rank 0 prints the one line (all legs of the default mode, the split ones included)."""
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--share-gpu",
+           "--size", "96", "--batch", "2", "--steps", "2", "--warmup", "1", "--cpu-frames", "0",
+           "--train-size", "64", "--train-batch", "2", "--syncbn-size", "96", "--syncbn-batch", "2", "--train-steps", "2"]
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    lines = [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout.decode()
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["config"]["global_batch"] == 4 and r["value"] > 0 and r["scaling"] == "weak"
+    for leg in ("also_infer96_split", "also_train416", "also_train416_split", "also_syncbn608"):
+        assert leg in r and r[leg]["n_gpus"] == 2, leg
+    assert r["also_train416_split"]["frames_per_s"] > 0 and r["also_infer96_split"]["frames_per_s"] > 0
+
+
 def test_default_bench_line_has_the_training_leg_on_one_gpu():
     """N = 1, default mode (small shapes): also_train416 present with a measured `traffic` when rocprofv3 exists."""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
