@@ -311,8 +311,12 @@ __device__ __forceinline__ void put_entry(const DetArgs& d, Entry* ent, SelState
   ent[slot] = e;
 }
 
-// sweep of the cached scores after pass 0: higher buckets -> entries, the selected bucket -> key list
-__global__ __launch_bounds__(kHistThreads) void compact_kernel(const DetArgs d, void* scratch, int n_items) {
+// sweep of the cached scores after pass 0: higher buckets -> entries, the selected bucket -> key list.
+// IPT anchor items per thread; blockIdx.z takes `cg_per_z` groups of 8 classes.  A big batch uses 4 items per thread and all
+// classes in one block; a small one (fewer blocks than CUs that way: one frame at 608 x 608 is 23 blocks, 37 us of
+// dependent round trips) one item and one class group per thread.
+template <int IPT>
+__global__ __launch_bounds__(kHistThreads) void compact_kernel(const DetArgs d, void* scratch, int n_items, int cg_per_z) {
   const int b = blockIdx.y;
   Scratch sc = carve(scratch, d.B);
   SelState* stp = sc.st + b;
@@ -321,16 +325,18 @@ __global__ __launch_bounds__(kHistThreads) void compact_kernel(const DetArgs d, 
   const bool fits = stp->bucket_n <= kListCap;
   Entry* ent = sc.ent + (size_t)b * VY_NMS_MAX_TOPK;
   unsigned long long* list = sc.list + (size_t)b * kListCap;
-  const int base = blockIdx.x * (kHistThreads * kItemsPerThread);
+  const int base = blockIdx.x * (kHistThreads * IPT);
+  const int c_begin = blockIdx.z * cg_per_z * 8;
+  const int c_end = c_begin + cg_per_z * 8 < d.C ? c_begin + cg_per_z * 8 : d.C;
 #pragma unroll 1
-  for (int q = 0; q < kItemsPerThread; ++q) {
+  for (int q = 0; q < IPT; ++q) {
     const int it = base + q * kHistThreads + threadIdx.x;
     Item im;
     if (it >= n_items || !locate(d, b, it, im)) continue;
     const float* cache = sc.score + (size_t)b * d.C * n_items + it;
     // eight classes' scores in flight per round trip (one load per iteration made the sweep latency-bound at small
     // batches: 45 us for one frame's 1.8 MB)
-    for (int c0 = 0; c0 < d.C; c0 += 8) {
+    for (int c0 = c_begin; c0 < c_end; c0 += 8) {
       float s8[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u) s8[u] = (c0 + u < d.C) ? cache[(size_t)(c0 + u) * n_items] : 0.0f;
@@ -444,18 +450,32 @@ __global__ __launch_bounds__(kBins) void refine_kernel(const DetArgs d, void* sc
   }
 }
 
-constexpr int kNmsThreads = 512;
+constexpr int kNmsThreads = 1024;
+
+#ifdef VY_NMS_TRACE  // tools/nms_latency.py --trace: phase stamps of image 0's workgroup (100 MHz realtime counter)
+__device__ unsigned long long vy_nms_trace_buf[16];
+#define NMS_STAMP(n) do { if (t == 0 && b == 0) vy_nms_trace_buf[n] = __builtin_amdgcn_s_memrealtime(); } while (0)
+extern "C" int vy_debug_nms_trace(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(vy_nms_trace_buf), sizeof(vy_nms_trace_buf));
+}
+#else
+#define NMS_STAMP(n) do { } while (0)
+#endif
 
 // one workgroup per image: sort the <= topk collected entries by key (descending), greedy
 // per-class suppression in that order, compact, write the first `rows` rows.
+// (round 4: at batch 1 this workgroup is 5 % of the frame's latency — 91 us for 400 candidates of one class, measured by
+// phase with -DVY_NMS_TRACE: bitonic sort 12, pair mask 53, greedy pass 23.  Now: 1024 threads; rank sort without
+// barriers; the pair mask enumerated over the words that can hold a later candidate only; the greedy pass word by
+// word — a 32-step scalar chain inside a word, its survivors applied to all later words at once.)
 __global__ __launch_bounds__(kNmsThreads) void sort_nms_kernel(const DetArgs d, void* scratch, int rows, float* ids,
                                                                float* scores, float* bboxes, int32_t* keep_idx) {
+  static_assert(kNmsThreads == VY_NMS_MAX_TOPK, "one candidate per thread");
   const int b = blockIdx.x;
   Scratch sc = carve(scratch, d.B);
   const SelState st = sc.st[b];
   const Entry* ent = sc.ent + (size_t)b * VY_NMS_MAX_TOPK;
-  __shared__ unsigned long long key[VY_NMS_MAX_TOPK];
-  __shared__ uint16_t perm[VY_NMS_MAX_TOPK];
+  __shared__ __attribute__((aligned(16))) unsigned long long key[VY_NMS_MAX_TOPK];
   __shared__ float bx1[VY_NMS_MAX_TOPK], by1[VY_NMS_MAX_TOPK], bx2[VY_NMS_MAX_TOPK], by2[VY_NMS_MAX_TOPK];
   __shared__ float bcls[VY_NMS_MAX_TOPK];
   __shared__ uint8_t alive[VY_NMS_MAX_TOPK];
@@ -463,96 +483,116 @@ __global__ __launch_bounds__(kNmsThreads) void sort_nms_kernel(const DetArgs d, 
   constexpr int kMaskRows = 416;  // pairwise suppression bits for up to 416 candidates (13 words each): 21 KiB
   __shared__ uint32_t mask[kMaskRows][13];
   const int t = threadIdx.x;
+  NMS_STAMP(0);
   int k = st.k_eff;
   if (k > VY_NMS_MAX_TOPK) k = VY_NMS_MAX_TOPK;
-  int kp = 1;
-  while (kp < k) kp <<= 1;
-  for (int i = t; i < kp; i += kNmsThreads) {
+  Entry e = {};
+  unsigned long long my_key = 0ull;  // key 0 (slots at and past k) is below every valid key: valid keys have sbits > 0
+  if (t < k) {
+    e = ent[t];
+    my_key = ((unsigned long long)e.sbits << 32) | e.inv;
+  }
+  key[t] = my_key;
+  pos[t] = 0;
+  __syncthreads();
+  NMS_STAMP(1);
+  // Rank sort, descending: the keys are distinct (their low half is the candidate index), so a candidate's place is the
+  // number of larger keys.  All 1024 threads count: candidate t & (kp - 1), a 1 / G slice of the keys each, four keys
+  // per step (two 16-byte LDS reads of addresses the whole wave shares: broadcasts); no barrier until the ranks are
+  // complete.  (The bitonic network this replaces: 45 barrier-separated passes for 400 candidates, 12 us.)
+  {
+    int kp = 1;
+    while (kp < k) kp <<= 1;
+    const int G = kNmsThreads / kp, i = t & (kp - 1), part = t / kp;
+    const int len = (((k + G - 1) / G) + 3) & ~3;
     if (i < k) {
-      key[i] = ((unsigned long long)ent[i].sbits << 32) | ent[i].inv;
-      perm[i] = (uint16_t)i;
-    } else {
-      key[i] = 0ull;  // sorts last (valid keys have sbits > 0)
-      perm[i] = 0;
-    }
-  }
-  __syncthreads();
-  // bitonic sort, descending
-  for (int size = 2; size <= kp; size <<= 1) {
-    for (int stride = size >> 1; stride > 0; stride >>= 1) {
-      for (int i = t; i < (kp >> 1); i += kNmsThreads) {
-        const int lo = ((i / stride) * (stride << 1)) + (i % stride);
-        const int hi = lo + stride;
-        const bool desc = ((lo & size) == 0);
-        const unsigned long long a = key[lo], c = key[hi];
-        if ((a < c) == desc) {
-          key[lo] = c;
-          key[hi] = a;
-          const uint16_t pa = perm[lo];
-          perm[lo] = perm[hi];
-          perm[hi] = pa;
-        }
+      typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+      const unsigned long long my = key[i];
+      const int k4 = (k + 3) & ~3;  // <= 1024: slots k .. k4 hold 0
+      int j = part * len, cnt = 0;
+      const int j_end = j + len < k4 ? j + len : k4;
+      for (; j < j_end; j += 4) {
+        const u64x2 a = *reinterpret_cast<const u64x2*>(&key[j]), c = *reinterpret_cast<const u64x2*>(&key[j + 2]);
+        cnt += (a[0] > my ? 1 : 0) + (a[1] > my ? 1 : 0) + (c[0] > my ? 1 : 0) + (c[1] > my ? 1 : 0);
       }
-      __syncthreads();
+      if (cnt) atomicAdd(&pos[i], cnt);
     }
   }
-  for (int i = t; i < k; i += kNmsThreads) {
-    const Entry e = ent[perm[i]];
-    bx1[i] = e.x1;
-    by1[i] = e.y1;
-    bx2[i] = e.x2;
-    by2[i] = e.y2;
-    bcls[i] = e.cls;
-    alive[i] = 1;
+  __syncthreads();
+  NMS_STAMP(2);
+  if (t < k) {
+    const int r = pos[t];
+    key[r] = my_key;  // every key[] was read before the barrier above
+    bx1[r] = e.x1;
+    by1[r] = e.y1;
+    bx2[r] = e.x2;
+    by2[r] = e.y2;
+    bcls[r] = e.cls;
+    alive[r] = 1;
   }
   __syncthreads();
+  NMS_STAMP(3);
   if (d.do_nms && k <= kMaskRows) {
-    // the usual case (topk 400): all pairwise "i would suppress j" bits in parallel, then the greedy pass — whose
-    // only serial dependency is the alive mask — by one wave, a 32-candidate word per lane (round 1: one
-    // workgroup barrier per surviving candidate, 165 us per batch)
+    // the usual case (topk 400): all pairwise "i would suppress j" bits in parallel, then the greedy pass, whose only
+    // serial dependency is the alive mask.  Word w of row i is needed only if it can hold a j > i: i < 32 (w + 1).
+    // Items are enumerated word by word, rows innermost: a wave works on consecutive rows of one word and reads the
+    // same candidate j in every step (LDS broadcasts), its lanes differ only in the row they hold in registers.
     const int words = (k + 31) >> 5;
-    for (int idx = t; idx < k * words; idx += kNmsThreads) {
-      const int i = idx / words, w = idx - i * words;
+    const int full = k >> 5;  // words w with 32 (w + 1) <= k
+    const int total = 16 * full * (full + 1) + (words > full ? k : 0);
+    for (int idx = t; idx < total; idx += kNmsThreads) {
+      int w = 0, i = idx;
+      for (;;) {
+        const int n_w = 32 * (w + 1) < k ? 32 * (w + 1) : k;
+        if (i < n_w) break;
+        i -= n_w;
+        ++w;
+      }
+      const float ac = bcls[i], ax1 = bx1[i], ay1 = by1[i], ax2 = bx2[i], ay2 = by2[i];
       uint32_t m = 0;
-      if (32 * w + 31 > i) {  // words wholly at or before candidate i hold no j > i
-        const float ac = bcls[i];
-        // first the cheap part for all 32 candidates of the word — later, in range, same class — then the IoU only
-        // for the set bits: a wave pays for the longest list among its lanes, not for 32 divergent iterations
-        uint32_t cm = 0;
-#pragma unroll 8
-        for (int bit = 0; bit < 32; ++bit) {
-          const int j = 32 * w + bit;
-          cm |= (uint32_t)(j > i && j < k && bcls[j] == ac) << bit;
-        }
-        const float ax1 = bx1[i], ay1 = by1[i], ax2 = bx2[i], ay2 = by2[i];
-        while (cm) {
-          const int bit = __builtin_ctz(cm);
-          cm &= cm - 1;
-          const int j = 32 * w + bit;
-          if (vy_box_iou(ax1, ay1, ax2, ay2, bx1[j], by1[j], bx2[j], by2[j]) > d.nms_thresh) m |= 1u << bit;
-        }
+#pragma unroll 4
+      for (int bit = 0; bit < 32; ++bit) {
+        const int j = 32 * w + bit;
+        if (j > i && j < k && bcls[j] == ac &&
+            vy_box_iou(ax1, ay1, ax2, ay2, bx1[j], by1[j], bx2[j], by2[j]) > d.nms_thresh)
+          m |= 1u << bit;
       }
       mask[i][w] = m;
     }
     __syncthreads();
+    NMS_STAMP(4);
     if (t < 64) {
+      // alive bits: word l in lane l.  Words are settled in order.  Word wb, once every earlier survivor has been applied
+      // to it: a 32-step chain over its own candidates on the scalar unit (lane l holds the diagonal word of row 32 wb + l,
+      // v_readlane with a constant lane), then the rows of its survivors are or-ed into all later words at once
+      // (32 independent LDS reads per lane, selected by an all-ones / all-zeros scalar).  Rows at or past k are never
+      // selected (their alive bits start as 0); mask[i][w] with w < i / 32 is never read.
       uint32_t aw = 0;
       if (t < words) aw = (32 * t + 32 <= k) ? 0xffffffffu : ((1u << (k - 32 * t)) - 1u);
-      // candidate i's alive bit lives in lane i / 32: a scalar-indexed v_readlane (a few cycles; __shfl would be a
-      // ds_bpermute round trip per candidate), and the mask rows of 16 candidates are read ahead of their use
       const int tw = t < words ? t : 0;
-      for (int i0 = 0; i0 < k; i0 += 16) {
-        uint32_t mrow[16];
+      for (int wb = 0; wb < words; ++wb) {
+        uint32_t cur = (uint32_t)__builtin_amdgcn_readlane((int)aw, wb);
+        if (cur == 0u) continue;  // uniform
+        const int di = 32 * wb + (t & 31);
+        const uint32_t diag = di < k ? mask[di][wb] : 0u;
+        if (__builtin_amdgcn_ballot_w64(diag != 0u) != 0ull) {  // (no pair inside this word overlaps: nothing to settle)
 #pragma unroll
-        for (int u = 0; u < 16; ++u) mrow[u] = (i0 + u < k) ? mask[i0 + u][tw] : 0u;
-#pragma unroll
-        for (int u = 0; u < 16; ++u) {
-          const int i = i0 + u;  // rows past k were read as 0: no early exit, so that mrow[] stays in registers
-          // branch-free: the row is applied through an all-ones / all-zeros scalar (lanes >= words carry aw = 0)
-          const uint32_t wi = (uint32_t)__builtin_amdgcn_readlane((int)aw, i >> 5);
-          const uint32_t sel = 0u - ((wi >> (i & 31)) & 1u);
-          aw &= ~(mrow[u] & sel);
+          for (int bit = 0; bit < 32; ++bit) {
+            const uint32_t row = (uint32_t)__builtin_amdgcn_readlane((int)diag, bit);
+            const uint32_t sel = 0u - ((cur >> bit) & 1u);
+            cur &= ~(row & sel);
+          }
         }
+        uint32_t acc0 = 0u, acc1 = 0u;
+        if (wb + 1 < words) {
+#pragma unroll
+          for (int bit = 0; bit < 32; bit += 2) {
+            acc0 |= mask[32 * wb + bit][tw] & (0u - ((cur >> bit) & 1u));
+            acc1 |= mask[32 * wb + bit + 1][tw] & (0u - ((cur >> (bit + 1)) & 1u));
+          }
+        }
+        if (t == wb) aw = cur;
+        else if (t > wb) aw &= ~(acc0 | acc1);
       }
       if (t < words)
         for (int bit = 0; bit < 32 && 32 * t + bit < k; ++bit) alive[32 * t + bit] = (uint8_t)((aw >> bit) & 1u);
@@ -571,20 +611,19 @@ __global__ __launch_bounds__(kNmsThreads) void sort_nms_kernel(const DetArgs d, 
       __syncthreads();
     }
   }
-  // compaction: exclusive scan of alive[] (k <= 1024, two elements per thread)
-  for (int i = t; i < VY_NMS_MAX_TOPK; i += kNmsThreads) pos[i] = (i < k && alive[i]) ? 1 : 0;
+  // compaction: inclusive scan of alive[] (k <= 1024, one element per thread)
+  NMS_STAMP(5);
+  __syncthreads();  // (the rank counters in pos[] were last read before the barriers above)
+  pos[t] = (t < k && alive[t]) ? 1 : 0;
   __syncthreads();
   for (int off = 1; off < VY_NMS_MAX_TOPK; off <<= 1) {
-    int v0 = 0, v1 = 0;
-    const int i0 = t, i1 = t + kNmsThreads;
-    if (i0 >= off) v0 = pos[i0 - off];
-    if (i1 >= off) v1 = pos[i1 - off];
+    const int v = t >= off ? pos[t - off] : 0;
     __syncthreads();
-    pos[i0] += v0;
-    pos[i1] += v1;
+    pos[t] += v;
     __syncthreads();
   }
   const int n_keep = pos[VY_NMS_MAX_TOPK - 1];
+  NMS_STAMP(6);
   for (int i = t; i < k; i += kNmsThreads) {
     if (!alive[i]) continue;
     const int r = pos[i] - 1;
@@ -608,6 +647,7 @@ __global__ __launch_bounds__(kNmsThreads) void sort_nms_kernel(const DetArgs d, 
     bboxes[o * 4 + 3] = -1.0f;
     if (keep_idx) keep_idx[o] = -1;
   }
+  NMS_STAMP(7);
 }
 
 
@@ -934,7 +974,13 @@ hipError_t vy_launch_detect(const DetArgs& a, void* scratch, float* ids, float* 
   }
   hipLaunchKernelGGL(hist_kernel, hgrid, dim3(kHistThreads), 0, s, a, scratch, 0, n_items);
   hipLaunchKernelGGL(select_kernel, dim3(a.B), dim3(kBins), 0, s, a, scratch, 0);
-  hipLaunchKernelGGL(compact_kernel, grid, dim3(kHistThreads), 0, s, a, scratch, n_items);
+  const int c_groups = (a.C + 7) / 8;
+  if ((long long)grid.x * a.B < 256) {
+    hipLaunchKernelGGL(compact_kernel<1>, dim3((n_items + kHistThreads - 1) / kHistThreads, a.B, c_groups), dim3(kHistThreads), 0, s,
+                       a, scratch, n_items, 1);
+  } else {
+    hipLaunchKernelGGL(compact_kernel<kItemsPerThread>, grid, dim3(kHistThreads), 0, s, a, scratch, n_items, c_groups);
+  }
   hipLaunchKernelGGL(refine_kernel, dim3(a.B), dim3(kBins), 0, s, a, scratch, n_items);
   hipLaunchKernelGGL(sort_nms_kernel, dim3(a.B), dim3(kNmsThreads), 0, s, a, scratch, rows, ids, scores, bboxes,
                      keep_idx);
