@@ -706,7 +706,7 @@ def main():
                              conv_mode="split_bf16x3_train")
             sleg["dtype"] = SPLIT_DTYPE + " (recorded forward, data gradients, weight gradients of the convs with cout % 128 == 0)"
             sleg["speedup_over_exact"] = sleg["frames_per_s"] / leg["frames_per_s"]
-            sleg["workload"] = leg["workload"] + "; net.set_conv_mode('split_bf16x3')"
+            sleg["workload"] = leg["workload"] + "; net.set_conv_mode('split_bf16x3_train')"
             result["also_train416_split"] = sleg   # named like also_train416 (the leg carries its size)
         if world > 1 or forced:
             leg = train_leg(vy, dev, dist, rank, world, args.syncbn_size, args.syncbn_batch, args.classes,

@@ -170,6 +170,35 @@ def test_random_configurations(ncls, batch, h, w, thr, topk, post, obj_bias):
     np.testing.assert_allclose(bboxes[fin], r[2][fin], rtol=0, atol=TOL)
 
 
+@pytest.mark.parametrize("ncls,obj_bias", [(1, 0.0), (3, 0.0), (2, -2.0)])
+def test_topk_around_word_boundaries(ncls, obj_bias):
+    """sort_nms keeps its pair mask in 32-candidate words, counts ranks in slices of the candidate list that depend on the
+    next power of two, and falls back to a serial pass above 416 candidates: nms_topk on and around every one of those
+    boundaries (and post_nms below / above the survivors), one class (everything may suppress everything) and several.
+    The oracle's detection tensor is computed once per case; box_nms per setting."""
+    from videoyolo_amd import init
+    from oracle import yolo3_oracle as O
+    classes = ["c%d" % i for i in range(ncls)]
+    params = init.synthetic_params(O.param_shapes(ncls), seed=77 + ncls, obj_bias=obj_bias)
+    x = frames(2, 96, seed=5)
+    net = _net(classes, params)
+    orc = O.OracleYolo3(ncls, params)
+    det = orc.detections(x)
+    for topk, post, thr in [(1, 1, 0.45), (2, 2, 0.45), (3, 100, 0.3), (31, 100, 0.45), (32, 100, 0.45), (33, 100, 0.45),
+                            (63, 10, 0.6), (64, 100, 0.45), (65, 100, 0.45), (127, 100, 0.45), (128, 100, 0.3), (129, 200, 0.45),
+                            (255, 100, 0.45), (256, 300, 0.45), (257, 100, 0.6), (384, 100, 0.45), (415, 100, 0.45),
+                            (416, 416, 0.45), (417, 100, 0.45), (512, 100, 0.45), (1023, 100, 0.3), (1024, 500, 0.45)]:
+        net.set_nms(thr, topk, post)
+        ids, scores, bboxes, keep = [t.cpu().numpy() for t in net(x, return_index=True)]
+        orc.nms_thresh, orc.nms_topk, orc.post_nms = thr, topk, post
+        r = orc.nms(det)
+        assert np.array_equal(keep, r[3]), (topk, post, thr)
+        assert np.array_equal(ids, r[0]), (topk, post, thr)
+        np.testing.assert_allclose(scores, r[1], rtol=0, atol=TOL)
+        fin = np.isfinite(r[2])
+        np.testing.assert_allclose(bboxes[fin], r[2][fin], rtol=0, atol=TOL)
+
+
 def test_ties_and_empty():
     """Degenerate inputs: all-zero weights give every candidate the SAME score (0.25): the order
     must fall back to the reference row index; a very negative objectness bias leaves no valid

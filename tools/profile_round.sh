@@ -27,6 +27,8 @@ python3 $R/tools/layer_profile.py --conv-mode split_bf16x3 --out $O/${tag}_layer
 python3 $R/tools/layer_profile.py --batch 1 --out $O/${tag}_layers_608_b1.txt > /dev/null 2>&1
 python3 $R/tools/layer_profile.py --batch 1 --conv-mode split_bf16x3 --out $O/${tag}_layers_608_b1_split.txt > /dev/null 2>&1
 bash $R/tools/ab_split_train.sh > $O/${tag}_ab_split_train.txt 2>&1
+bash $R/tools/ab_split_train_prof.sh > $O/${tag}_train416_b16_split_kernel_totals.txt 2>&1
+python3 $R/tools/nms_latency.py > $O/${tag}_nms_latency.txt 2>&1
 python3 $R/tools/small_batch_latency.py > $O/${tag}_small_batch_latency.txt 2>&1
 python3 $R/tools/small_batch_latency.py --conv-mode split_bf16x3 > $O/${tag}_small_batch_latency_split.txt 2>&1
 $R/tools/train_layers.sh ${tag}

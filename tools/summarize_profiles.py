@@ -38,6 +38,8 @@ for src, dst in [("%s_infer608_b64_bench.json", "%s_infer608_b64_bench.json"),
                  ("%s_layers_608_b1.txt", "%s_layers_608_b1.txt"),
                  ("%s_layers_608_b1_split.txt", "%s_layers_608_b1_split.txt"),
                  ("%s_ab_split_train.txt", "%s_ab_split_train.txt"),
+                 ("%s_train416_b16_split_kernel_totals.txt", "%s_train416_b16_split_kernel_totals.txt"),
+                 ("%s_nms_latency.txt", "%s_nms_latency.txt"),
                  ("%s_small_batch_latency_split.txt", "%s_small_batch_latency_split.txt"),
                  ("%s_layers.txt", "%s_train416_b16_layers.txt")]:
     if os.path.exists(os.path.join(G, src % tag)):
