@@ -445,7 +445,9 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(const ConvArgs a, co
       rd_w(1);
       prod(2, 0);
       prod(0, 2);
+#if !defined(VY_SPLIT_DROP_MM)  // (probe builds only: the five-product variant, profiles/r04_negative_results.txt)
       prod(1, 1);
+#endif
       prod(1, 0);
       prod(0, 1);
       prod(0, 0);
