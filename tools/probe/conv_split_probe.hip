@@ -146,10 +146,11 @@ int main(int argc, char** argv) {
   CK(hipEventCreate(&e1));
   const double K = (double)k * k * Cin, gflop = 2.0 * a.M * (double)Cout * K * 1e-9;
   float ms_e = 0, ms_s = 0;
+  const bool split_only = getenv("VY_PROBE_SPLIT_ONLY") != nullptr;  // (power / clock sampling: one exact launch per round)
   for (int round = 0; round < 2; ++round) {  // interleaved: exact, split, exact, split
     for (int i = 0; i < 3; ++i) CK(vy_launch_conv_igemm(a, 0));
     CK(hipEventRecord(e0, 0));
-    for (int i = 0; i < reps; ++i) CK(vy_launch_conv_igemm(a, 0));
+    for (int i = 0; i < (split_only ? 1 : reps); ++i) CK(vy_launch_conv_igemm(a, 0));
     CK(hipEventRecord(e1, 0));
     CK(hipEventSynchronize(e1));
     CK(hipEventElapsedTime(&ms_e, e0, e1));
@@ -159,7 +160,7 @@ int main(int argc, char** argv) {
     CK(hipEventRecord(e1, 0));
     CK(hipEventSynchronize(e1));
     CK(hipEventElapsedTime(&ms_s, e0, e1));
-    const double us_e = ms_e * 1e3 / reps, us_s = ms_s * 1e3 / reps;
+    const double us_e = ms_e * 1e3 / (split_only ? 1 : reps), us_s = ms_s * 1e3 / reps;
     int sbm, sbn, sks;
     vy_conv_split_cfg(a2, &sbm, &sbn, &sks);
     printf("[%dx%d k%d] ", sbm, sbn, sks);
