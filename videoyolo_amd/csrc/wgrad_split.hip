@@ -146,27 +146,39 @@ __global__ __launch_bounds__(256, 2) void wgrad_split_kernel(const WgradArgs a, 
   };
   auto compute = [&](int stage) {
     ws_bf16x8 af[3][2], bf[3][2];
-#pragma unroll
-    for (int p = 0; p < 3; ++p)
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        af[p][i] = tr8(fa0 + stage * STAGE + p * PLANE + i * 64);
-        bf[p][i] = tr8(fb0 + stage * STAGE + p * PLANE + i * 64);
-      }
-    // the reads above are inline asm: the compiler neither counts them nor keeps the MFMAs behind a wait of its own
-#pragma unroll
-    for (int p = 0; p < 3; ++p)
-#pragma unroll
-      for (int i = 0; i < 2; ++i) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[p][i]), "+v"(bf[p][i])::"memory");
-    __builtin_amdgcn_sched_barrier(0);
     constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};  // (l,h) (h,l) (m,m) (m,h) (h,m) (h,h)
-#pragma unroll
-    for (int t = 0; t < 6; ++t)
+    auto prod = [&](int t) {
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[PA[t]][i], bf[PB[t]][j], acc[i][j], 0, 0, 0);
+    };
+    // The reads are inline asm (the compiler neither counts them nor keeps the MFMAs behind a wait of its own), issued in
+    // the order the products need them — (a_l, b_h) (a_h, b_l) (a_m, b_m), eight ds_reads each — and a product starts as
+    // soon as its group has landed (LDS returns in order; lgkmcnt holds at most 15).  One wait for all 24 reads before
+    // the first MFMA was 7 % slower (166 -> 155 us on the 52x52 128->256 layer); finer steps, or the reads issued ahead of
+    // the next k-step's split arithmetic, were slower again (160 / 195 us): tools/probe/run_wgrad_staged.sh.
+    constexpr int RA[3] = {2, 0, 1}, RB[3] = {0, 2, 1};
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        af[RA[g]][i] = tr8(fa0 + stage * STAGE + RA[g] * PLANE + i * 64);
+        bf[RB[g]][i] = tr8(fb0 + stage * STAGE + RB[g] * PLANE + i * 64);
+      }
+    asm volatile("s_waitcnt lgkmcnt(15)" : "+v"(af[2][0]), "+v"(af[2][1]), "+v"(bf[0][0]), "+v"(bf[0][1])::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    prod(0);
+    asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(af[0][0]), "+v"(af[0][1]), "+v"(bf[2][0]), "+v"(bf[2][1])::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    prod(1);
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[1][0]), "+v"(af[1][1]), "+v"(bf[1][0]), "+v"(bf[1][1])::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    prod(2);
+    prod(3);
+    prod(4);
+    prod(5);
   };
 
   if (T > 0) {
