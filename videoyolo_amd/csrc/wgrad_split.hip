@@ -11,7 +11,8 @@
 // Both operands are activations, pixel-major in memory (NHWC planes), and BOTH are split in registers on the way into
 // LDS: per k-step of 16 pixels a thread loads 8 dz channels and 8 input channels of one pixel, cuts them into the three
 // planes (2 x 44 vector instructions) and stores 6 x 16 B.  The MFMA fragments need 8 consecutive k (pixels) of one
-// channel: `ds_read_b64_tr_b16` delivers a 4-pixel x 16-channel block column-major, two reads per fragment.  LDS image
+// channel: `ds_read_b64_tr_b16` (through hipcc's builtin) delivers a 4-pixel x 16-channel block column-major, two reads per
+// fragment.  LDS image
 // per operand and stage: [plane][16 pixels][128 channels + 32 pad] bf16 — the 320-B row pitch puts the four pixel rows
 // of a transposed read on disjoint banks.  Two stages (60 KiB): two blocks per CU.
 #include <cstdio>
@@ -22,7 +23,6 @@
 
 #if defined(__HIP_DEVICE_COMPILE__)
 typedef __bf16 ws_bf16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned ws_u32x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ unsigned ws_cvt_pk_bf16(float lo, float hi) {
   unsigned r;
@@ -137,11 +137,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_split_kernel(const WgradArgs a, 
   const unsigned lds0 = (unsigned)(unsigned long long)LDS_PTR(smem);
   const unsigned fa0 = lds0 + tr_off + (unsigned)(wm * 64 * 2);         // A tile of this wave: channels wm*64 ..
   const unsigned fb0 = lds0 + IMG + tr_off + (unsigned)(wn * 64 * 2);   // B tile: columns wn*64 ..
+  typedef short ws_s16x4 __attribute__((ext_vector_type(4)));
+  typedef short ws_s16x8 __attribute__((ext_vector_type(8)));
   auto tr8 = [&](unsigned addr) -> ws_bf16x8 {
-    ws_u32x2 lo, hi;
-    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(addr) : "memory");
-    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:1280" : "=v"(hi) : "v"(addr) : "memory");  // + 4 pixel rows
-    vy_u32x4 v = {lo[0], lo[1], hi[0], hi[1]};
+    const ws_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) ws_s16x4*)(unsigned long long)addr);
+    const ws_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) ws_s16x4*)(unsigned long long)(addr + 1280));
+    const ws_s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     return __builtin_bit_cast(ws_bf16x8, v);
   };
   auto compute = [&](int stage) {
@@ -154,31 +155,19 @@ __global__ __launch_bounds__(256, 2) void wgrad_split_kernel(const WgradArgs a, 
         for (int j = 0; j < 2; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[PA[t]][i], bf[PB[t]][j], acc[i][j], 0, 0, 0);
     };
-    // The reads are inline asm (the compiler neither counts them nor keeps the MFMAs behind a wait of its own), issued in
-    // the order the products need them — (a_l, b_h) (a_h, b_l) (a_m, b_m), eight ds_reads each — and a product starts as
-    // soon as its group has landed (LDS returns in order; lgkmcnt holds at most 15).  One wait for all 24 reads before
-    // the first MFMA was 7 % slower (166 -> 155 us on the 52x52 128->256 layer); finer steps, or the reads issued ahead of
-    // the next k-step's split arithmetic, were slower again (160 / 195 us): tools/probe/run_wgrad_staged.sh.
-    constexpr int RA[3] = {2, 0, 1}, RB[3] = {0, 2, 1};
+    // The transposed reads go through the compiler's builtin, so that hipcc counts them and interleaves them with the
+    // MFMAs itself.  As inline asm with ONE hand-placed wait before the first MFMA the kernel was 10 % slower (166 against
+    // 150 us on the 52x52 128->256 layer), with hand-staged waits per product group 4 % slower (155 us); finer stages, or
+    // the reads issued ahead of the next k-step's split arithmetic, slower again (tools/probe/run_wgrad_staged.sh).
 #pragma unroll
-    for (int g = 0; g < 3; ++g)
+    for (int p = 0; p < 3; ++p)
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        af[RA[g]][i] = tr8(fa0 + stage * STAGE + RA[g] * PLANE + i * 64);
-        bf[RB[g]][i] = tr8(fb0 + stage * STAGE + RB[g] * PLANE + i * 64);
+        af[p][i] = tr8(fa0 + stage * STAGE + p * PLANE + i * 64);
+        bf[p][i] = tr8(fb0 + stage * STAGE + p * PLANE + i * 64);
       }
-    asm volatile("s_waitcnt lgkmcnt(15)" : "+v"(af[2][0]), "+v"(af[2][1]), "+v"(bf[0][0]), "+v"(bf[0][1])::"memory");
-    __builtin_amdgcn_sched_barrier(0);
-    prod(0);
-    asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(af[0][0]), "+v"(af[0][1]), "+v"(bf[2][0]), "+v"(bf[2][1])::"memory");
-    __builtin_amdgcn_sched_barrier(0);
-    prod(1);
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[1][0]), "+v"(af[1][1]), "+v"(bf[1][0]), "+v"(bf[1][1])::"memory");
-    __builtin_amdgcn_sched_barrier(0);
-    prod(2);
-    prod(3);
-    prod(4);
-    prod(5);
+#pragma unroll
+    for (int t = 0; t < 6; ++t) prod(t);
   };
 
   if (T > 0) {
