@@ -137,11 +137,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_presplit_kernel(const WgradArgs 
     fa[i] = lds0 + (unsigned)(trow * ROW + ((cca ^ sw) << 4) + (i16 & 1) * 8);
     fb[i] = lds0 + IMG + (unsigned)(trow * ROW + ((ccb ^ sw) << 4) + (i16 & 1) * 8);
   }
-  auto tr8 = [&](unsigned addr) -> ws_bf16x8 {
-    ws_u32x2 lo, hi;
-    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(addr) : "memory");
-    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:1024" : "=v"(hi) : "v"(addr) : "memory");  // + 4 pixel rows
-    vy_u32x4 v = {lo[0], lo[1], hi[0], hi[1]};
+  typedef short ps_s16x4 __attribute__((ext_vector_type(4)));
+  typedef short ps_s16x8 __attribute__((ext_vector_type(8)));
+  auto tr8 = [&](unsigned addr) -> ws_bf16x8 {  // hipcc's builtin: the compiler schedules the reads against the MFMAs
+    const ps_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) ps_s16x4*)(unsigned long long)addr);
+    const ps_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) ps_s16x4*)(unsigned long long)(addr + 1024));
+    const ps_s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     return __builtin_bit_cast(ws_bf16x8, v);
   };
   auto compute = [&](int stage) {
@@ -153,11 +154,6 @@ __global__ __launch_bounds__(256, 2) void wgrad_presplit_kernel(const WgradArgs 
         af[p][i] = tr8(fa[i] + stage * STAGE + p * PLANE);
         bf[p][i] = tr8(fb[i] + stage * STAGE + p * PLANE);
       }
-#pragma unroll
-    for (int p = 0; p < 3; ++p)
-#pragma unroll
-      for (int i = 0; i < 2; ++i) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[p][i]), "+v"(bf[p][i])::"memory");
-    __builtin_amdgcn_sched_barrier(0);
     constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};  // (l,h) (h,l) (m,m) (m,h) (h,m) (h,h)
 #pragma unroll
     for (int t = 0; t < 6; ++t)
