@@ -25,7 +25,7 @@
 //      to the entries.  Only when the bucket overflows the list (degenerate inputs: every score equal) does
 //      this kernel walk the whole score cache instead.  (Round 1 swept all cached scores in each of the six
 //      refinement passes and once more to collect: 16 launches, 6x the bytes.)
-//   5. sort_nms: one workgroup per image: bitonic sort by key, greedy per-class IoU suppression,
+//   5. sort_nms: one workgroup per image: rank sort by key, pair mask + word-wise greedy per-class IoU suppression,
 //      compaction, write the first post_nms rows (-1 filler).
 // HBM-bound integer/byte work: coalesced channel-contiguous reads, LDS histograms, no MFMA.
 #include "kernels.h"
