@@ -1,7 +1,7 @@
 """The reference's training loop (train_yolov3.py:494-640) on this package with synthetic VOC-shaped batches; with
 --gpus N the script starts one process per GPU itself (RCCL), like `python train_yolov3.py --gpus 0,1,..`.
 
-    python examples/train.py [--gpus 1] [--batch 16] [--size 416] [--steps 5] [--syncbn]
+    python examples/train.py [--gpus 1] [--batch 16] [--size 416] [--steps 5] [--syncbn] [--conv-mode split_bf16x3_train]
 """
 import argparse
 import os
@@ -20,6 +20,8 @@ def main():
     ap.add_argument("--size", type=int, default=416)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--syncbn", action="store_true")
+    ap.add_argument("--conv-mode", default="exact", choices=["exact", "split_bf16x3_train"],
+                    help="split_bf16x3_train: opt-in split-fp32 convs and weight gradients on the bf16 matrix core (DESIGN.md 4.7, 4.8)")
     args = ap.parse_args()
     if launch.needs_spawn(args.gpus):            # this process only starts the ranks; it never touches a GPU
         sys.exit(launch.spawn_ranks(args.gpus, [os.path.abspath(__file__)] + sys.argv[1:]))
@@ -40,6 +42,7 @@ def main():
     net = vy.yolo3_darknet53(classes, pretrained_base=False, **kw)     # train_yolov3.py:350-360
     net.initialize()                                                   # unseeded, like the reference: Trainer() broadcasts rank 0's
     net.collect_params().reset_ctx(dev)
+    net.set_conv_mode(args.conv_mode)                                  # no counterpart in the reference (mxnet picks its conv algorithm)
     for p in net.collect_params(".*beta|.*gamma|.*bias").values():     # --no_wd, :495-497
         p.wd_mult = 0.0
     sched = vy.LRSequential([vy.LRScheduler("linear", base_lr=0, target_lr=1e-3, nepochs=0, iters_per_epoch=100, niters=2),

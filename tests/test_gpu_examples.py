@@ -31,8 +31,9 @@ def test_detect_example_in_the_split_conv_mode():
     assert exact.split("prediction lines")[0] == split.split("prediction lines")[0]
 
 
-def test_train_example(tmp_path):
-    out = _run(["examples/train.py", "--batch", "2", "--size", "96", "--steps", "3"])
+@pytest.mark.parametrize("mode", ["exact", "split_bf16x3_train"])
+def test_train_example(tmp_path, mode):
+    out = _run(["examples/train.py", "--batch", "2", "--size", "96", "--steps", "3", "--conv-mode", mode])
     steps = [l for l in out.splitlines() if l.startswith("step ")]
     assert len(steps) == 3 and "saved" in out
     vals = [float(l.split("obj")[1].split()[0]) for l in steps]
