@@ -242,7 +242,7 @@ int main(int argc, char** argv) {
   const int Ho = H / stride;
   const int M = B * Ho * Ho, Ntot = k * k * Cin;
   if (splits <= 0) {  // about 1024 blocks
-    const int tiles = (Cout / 128) * ((Ntot + 127) / 128);
+    const int tiles = ((Cout + 127) / 128) * ((Ntot + 127) / 128);
     splits = std::max(1, 1024 / tiles);
   }
   int kps = ((M + splits - 1) / splits + 31) / 32 * 32;
