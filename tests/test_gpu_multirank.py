@@ -184,7 +184,7 @@ def test_bench_starts_its_own_ranks(extra):
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--share-gpu",
            "--size", "96", "--batch", "2", "--steps", "2", "--warmup", "1", "--cpu-frames", "0",
            "--train-size", "64", "--train-batch", "2", "--syncbn-size", "96", "--syncbn-batch", "2",
-           "--train-steps", "2"] + extra
+           "--train-steps", "2", "--no-split-leg"] + extra   # (the split legs at 2 ranks: test_bench_under_torch_distributed_run)
     p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
     assert p.returncode == 0, p.stderr.decode()[-2000:]
     lines = [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
