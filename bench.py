@@ -168,6 +168,8 @@ def launch_table(net, x):
     for name, ms, fl, by in med:
         if "|split" in name:  # "<cell>|split<BM>x<BN>": the bf16 x 3 instance (conv_split.hip)
             key = "conv_split_kernel<%s>" % name.split("|split")[1]
+        elif "|wino" in name:  # "<cell>|wino64x128": the same arithmetic as Winograd F(2, 3) (conv_wino.hip)
+            key = "conv_wino_kernel<%s>" % name.split("|wino")[1]
         elif "|" in name:  # conv launches are reported as "<cell>|<BM>x<BN>"
             key = "conv_igemm_kernel<%s>" % name.split("|")[1]
         else:
@@ -604,7 +606,7 @@ def main():
                            % (args.size, args.size, args.batch)}
         if rank == 0 and not args.no_roofline:
             smed, sagg = launch_table(net, x)
-            sp = [a for k, a in sagg.items() if k.startswith("conv_split_kernel")]
+            sp = [a for k, a in sagg.items() if k.startswith("conv_split_kernel") or k.startswith("conv_wino_kernel")]
             ex = [a for k, a in sagg.items() if k.startswith("conv_igemm_kernel")]
             sp_ms, sp_fl = sum(a[1] for a in sp), sum(a[2] for a in sp)
             tot_ms, tot_fl = sum(a[1] for a in sagg.values()), sum(a[2] for a in sagg.values())

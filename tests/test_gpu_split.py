@@ -171,6 +171,33 @@ def test_kernel_computes_the_six_products(voc_classes, synth20, name, src, k, st
     assert err5.max() > 4 * err6.max()
 
 
+@pytest.mark.parametrize("batch,h,w", [(2, 96, 96), (3, 160, 160), (1, 128, 224), (1, 416, 416)])
+def test_winograd_cells_forced_everywhere(voc_classes, synth20, batch, h, w, monkeypatch, capsys):
+    """conv_wino.hip — the long-K 3x3 stride-1 cells as a 1-D Winograd F(2, 3) on the same split arithmetic — is chosen by
+    the product only for launches of >= 1024 blocks; VY_SPLIT_WINO=2 sends EVERY supported cell through it (the 31 cells
+    of 128 output channels and more, residual adds included, at widths 3 ... 52: odd widths exercise the pair without a
+    second pixel).  Heads and layer taps within the split mode's bars, kept rows up to near-ties; =0 switches it off."""
+    monkeypatch.setenv("VY_SPLIT_WINO", "2")
+    rng = np.random.default_rng(h * 1000 + w)
+    x = rng.standard_normal((batch, 3, h, w)).astype(np.float32)
+    net = _net(voc_classes, synth20)
+    names = _split_launches(net, x)
+    assert sum("|wino" in n for n in names) == 31, [n for n in names if "|wino" in n]
+    ids, scores, bboxes, keep = [t.cpu().numpy() for t in net(x, return_index=True)]
+    orc = _oracle(synth20)
+    ref = orc.raw_heads(x)
+    worst = max(float(np.abs(net.read_head(i).cpu().numpy() - ref[i]).max()) for i in range(3))
+    with capsys.disabled():
+        print("\n[winograd %dx%dx%d] max |head - oracle| = %.3e (bar %.0e)" % (batch, h, w, worst, HEAD_TOL))
+    assert worst <= HEAD_TOL
+    r = orc(x)
+    exc = _check_keep(keep, r[3], orc.detections(x), "winograd %dx%dx%d" % (batch, h, w), capsys)
+    assert len(exc) <= 4
+    np.testing.assert_allclose(np.sort(scores, 1), np.sort(r[1], 1), rtol=0, atol=TOL)
+    monkeypatch.setenv("VY_SPLIT_WINO", "0")
+    assert not any("|wino" in n for n in _split_launches(net, x))
+
+
 @pytest.mark.parametrize("batch,size,obj_bias", [(2, 96, 0.0), (2, 128, -3.0), (1, 416, 0.0), (2, 160, -5.0)])
 def test_split_detections_match_oracle(voc_classes, batch, size, obj_bias, capsys):
     from videoyolo_amd import init
@@ -421,7 +448,8 @@ def test_split_inference_full_size(ncls, batch, obj_bias, monkeypatch, capsys):
     net = _net(classes, params)
     x = torch.as_tensor(frames(batch, 608, seed=7)).cuda()
     names = _split_launches(net, x)
-    assert sum("|split" in n for n in names) >= 67   # (a marginal 1x1 launch may stay on the exact kernel: the model decides)
+    assert sum("|split" in n or "|wino" in n for n in names) >= 67   # (a marginal 1x1 launch may stay on the exact kernel: the model decides)
+    assert sum("|wino" in n for n in names) >= 20                    # the long-K 3x3 stride-1 cells: Winograd F(2, 3) (conv_wino.hip)
     out = [t.clone() for t in net(x, return_index=True)]
     again = net(x, return_index=True)
     assert all(torch.equal(a, b) for a, b in zip(out, again)), "not reproducible run to run"

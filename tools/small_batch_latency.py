@@ -37,7 +37,7 @@ for b in [int(t) for t in a.batches.split(",")]:
     ms = (time.perf_counter() - t0) / n * 1e3
     names = [name for name, _, _, _ in net.profile(x)]
     sk = sum(1 for n_ in names if n_.endswith("sk"))
-    sp = sum(1 for n_ in names if "|split" in n_)
+    sp = sum(1 for n_ in names if "|split" in n_ or "|wino" in n_)
     spk = sum(1 for n_ in names if "|split" in n_ and "k" in n_.split("|split")[1])
     print("batch %2d: %7.3f ms  %7.1f frames/s  %5.1f TFLOP/s  (%d stream-K launches, %d split-fp32 launches of which %d k-split)"
           % (b, ms, b / ms * 1e3, (GF * b / ms) if GF else 0.0, sk, sp, spk))

@@ -14,8 +14,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libvyolo.so")
-SOURCES = ["net.hip", "train.hip", "conv_igemm.hip", "conv_split.hip", "conv_small.hip", "wgrad.hip", "wgrad_split.hip", "misc_kernels.hip", "train_kernels.hip", "detect.hip", "preproc.hip", "targets.hip"]
-HEADERS = [os.path.join(CSRC, "kernels.h"), os.path.join(CSRC, "net_internal.h"), os.path.join(CSRC, "conv_device.h"), os.path.join(CSRC, "sk_schedule.h"), os.path.join(CSRC, "conv_cost_model.h"),
+SOURCES = ["net.hip", "train.hip", "conv_igemm.hip", "conv_split.hip", "conv_wino.hip", "conv_small.hip", "wgrad.hip", "wgrad_split.hip", "misc_kernels.hip", "train_kernels.hip", "detect.hip", "preproc.hip", "targets.hip"]
+HEADERS = [os.path.join(CSRC, "kernels.h"), os.path.join(CSRC, "net_internal.h"), os.path.join(CSRC, "conv_device.h"), os.path.join(CSRC, "sk_schedule.h"), os.path.join(CSRC, "conv_cost_model.h"), os.path.join(CSRC, "split_device.h"),
            os.path.join(HERE, "..", "include", "vyolo.h"),
            os.path.join(HERE, "..", "include", "vy_math.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

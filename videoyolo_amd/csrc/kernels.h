@@ -56,6 +56,9 @@ struct ConvArgs {
   // sk_partials (a stream never runs a stream-K exact launch and a split-K launch at once); nullable: no k-split
   float* splitk_slabs;
   unsigned long long splitk_bytes;
+  // conv_wino.hip only: this conv's weights as four Winograd-transformed, pre-split image sets (vy_launch_wino_weights);
+  // nullable
+  const void* w_wino;
 };
 #define VY_SK_PARTIAL_BYTES (32u << 20)  // 512 blocks x 128x128 fp32 (the largest instance: 2 blocks per CU x 256 CUs)
 #define VY_SK_FLAGS 2048
@@ -93,6 +96,13 @@ struct SplitDesc {
 };
 hipError_t vy_launch_split_weights_batch(const float* params, void* ws, const SplitDesc* descs_dev, int n, long long total,
                                          hipStream_t s);
+// ... and, for its long-K 3x3 stride-1 cells, as a 1-D Winograd F(2, 3) on the same split arithmetic (conv_wino.hip;
+// a.w_wino = the transformed image sets)
+size_t vy_wino_weight_bytes(int cout, int cin);
+hipError_t vy_launch_wino_weights(const float* w, void* img, int cout, int cin, hipStream_t s);
+bool vy_conv_wino_supported(const ConvArgs& a);
+bool vy_conv_wino_pays(const ConvArgs& a);          // K = 9 Cin >= 1152 and a launch of >= 1024 blocks; VY_SPLIT_WINO=0 / 2
+hipError_t vy_launch_conv_wino(const ConvArgs& a, hipStream_t s);
 bool vy_conv_split_supported(const ConvArgs& a);   // forward, N % 64 == 0, Kc % 32 == 0, an epilogue the kernel has
 void vy_conv_split_cfg(const ConvArgs& a, int* bm, int* bn, int* ksplit);  // block tile and k-split the launch will use
 // conv mode VY_CONV_SPLIT_BF16X3, per launch: supported AND predicted faster than the exact kernel (small launches —

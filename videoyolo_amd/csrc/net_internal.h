@@ -46,6 +46,7 @@ struct ConvT {
   int p_bias;                     // -1 for cells
   int64_t scale_off, shift_off;   // folded BN scratch (element offsets), -1 if none
   int is_stem;
+  int64_t wino_off = -1;          // ... of its Winograd-transformed image sets (conv_wino.hip: 3x3 stride-1 cells with cout % 128 == 0), -1: none
   int64_t split_off = -1;         // conv mode VY_CONV_SPLIT_BF16X3: byte offset of the bf16 weight images in the workspace region, -1: exact kernel
 };
 
@@ -334,6 +335,9 @@ struct vy_net {
       const bool el = split_eligible(c);
       if (commit) c.split_off = el ? (int64_t)(off - wsp_off) : -1;
       if (el) off += al(vy_split_weight_bytes(c.cout, c.k * c.k, c.cin));
+      const bool wel = el && c.k == 3 && c.stride == 1 && c.ups == 1 && c.cout % 128 == 0;
+      if (commit) c.wino_off = wel ? (int64_t)(off - wsp_off) : -1;
+      if (wel) off += al(vy_wino_weight_bytes(c.cout, c.cin));
     }
     const size_t pl_off = off;
     size_t fl = 0;
@@ -432,6 +436,7 @@ struct vy_net {
     a.leaky = c.leaky;
     a.dgrad = 0;
     a.w_split = c.split_off >= 0 ? dev_ws + wsplit_off + c.split_off : nullptr;
+    a.w_wino = c.wino_off >= 0 ? dev_ws + wsplit_off + c.wino_off : nullptr;
     a.splitk_slabs = reinterpret_cast<float*>(dev_ws + sk_off + al((size_t)VY_SK_FLAGS * sizeof(unsigned)));
     a.splitk_bytes = VY_SK_PARTIAL_BYTES;
     set_sk(a);
@@ -513,6 +518,10 @@ struct vy_net {
         if (c.split_off >= 0)
           HIP_TRY(vy_launch_split_weights(dev_params + params[c.p_weight].info.offset, dev_ws + wsplit_off + c.split_off,
                                           c.cout, c.k * c.k, c.cin, s));
+      for (const ConvT& c : convs)
+        if (c.wino_off >= 0)
+          HIP_TRY(vy_launch_wino_weights(dev_params + params[c.p_weight].info.offset, dev_ws + wsplit_off + c.wino_off, c.cout,
+                                         c.cin, s));
       hook("split_weights", 0.0, 0.0, false);
       split_dirty = false;
     }
@@ -538,7 +547,9 @@ struct vy_net {
       } else {
         const ConvArgs a = conv_args(c);
         if (!kLabels) {  // plain forward: no label, no second tile / stream-K query per launch (batch-1 latency path)
-          if (a.w_split && vy_conv_split_pays(a))
+          if (a.w_wino && vy_conv_wino_pays(a))
+            HIP_TRY(vy_launch_conv_wino(a, s));
+          else if (a.w_split && vy_conv_split_pays(a))
             HIP_TRY(vy_launch_conv_split(a, s));
           else
             HIP_TRY(vy_launch_conv_igemm(a, s));
@@ -548,6 +559,13 @@ struct vy_net {
         const double by = 4.0 * ((double)B * (a.a_Hp - 2) * (a.a_Wp - 2) * a.Kc + (double)a.M * a.N * a.ups * a.ups +
                                  (double)a.N * a.ntaps * a.Kc + (a.res ? (double)a.M * a.N : 0.0));
         char nm[96];
+        if (a.w_wino && vy_conv_wino_pays(a)) {
+          snprintf(nm, sizeof nm, "%s|wino64x128", c.name.c_str());
+          hook(nm, fl, by, true);
+          HIP_TRY(vy_launch_conv_wino(a, s));
+          hook(nm, fl, by, false);
+          continue;
+        }
         if (a.w_split && vy_conv_split_pays(a)) {
           int sbm, sbn, sks;
           vy_conv_split_cfg(a, &sbm, &sbn, &sks);
