@@ -184,27 +184,32 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvArgs a, con
     };
     auto store_a = [&](int stage) {
       if (!a_active) return;
-      f32x4 u0, u1, v0, v1;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        if (PH == 0) {  // V0 = d0 - d2, V1 = d1 + d2
-          u0[e] = pa[0][e] - pc[0][e], u1[e] = pa[1][e] - pc[1][e];
-          v0[e] = pb[0][e] + pc[0][e], v1[e] = pb[1][e] + pc[1][e];
-        } else {        // V2 = d2 - d1, V3 = d1 - d3
-          u0[e] = pb[0][e] - pa[0][e], u1[e] = pb[1][e] - pa[1][e];
-          v0[e] = pa[0][e] - pc[0][e], v1[e] = pa[1][e] - pc[1][e];
-        }
-      }
       vy_u32x4 H, M, L;
       unsigned char* d = smem + stage * A_ST + a_lds;
-      split8(u0, u1, H, M, L);
-      *reinterpret_cast<vy_u32x4*>(d) = H;
-      *reinterpret_cast<vy_u32x4*>(d + A_PL) = M;
-      *reinterpret_cast<vy_u32x4*>(d + 2 * A_PL) = L;
-      split8(v0, v1, H, M, L);
-      *reinterpret_cast<vy_u32x4*>(d + A_XI) = H;
-      *reinterpret_cast<vy_u32x4*>(d + A_XI + A_PL) = M;
-      *reinterpret_cast<vy_u32x4*>(d + A_XI + 2 * A_PL) = L;
+      {
+        f32x4 u0, u1;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (PH == 0) u0[e] = pa[0][e] - pc[0][e], u1[e] = pa[1][e] - pc[1][e];  // V0 = d0 - d2
+          else u0[e] = pb[0][e] - pa[0][e], u1[e] = pb[1][e] - pa[1][e];           // V2 = d2 - d1
+        }
+        split8(u0, u1, H, M, L);
+        *reinterpret_cast<vy_u32x4*>(d) = H;
+        *reinterpret_cast<vy_u32x4*>(d + A_PL) = M;
+        *reinterpret_cast<vy_u32x4*>(d + 2 * A_PL) = L;
+      }
+      {
+        f32x4 v0, v1;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (PH == 0) v0[e] = pb[0][e] + pc[0][e], v1[e] = pb[1][e] + pc[1][e];  // V1 = d1 + d2
+          else v0[e] = pa[0][e] - pc[0][e], v1[e] = pa[1][e] - pc[1][e];           // V3 = d1 - d3
+        }
+        split8(v0, v1, H, M, L);
+        *reinterpret_cast<vy_u32x4*>(d + A_XI) = H;
+        *reinterpret_cast<vy_u32x4*>(d + A_XI + A_PL) = M;
+        *reinterpret_cast<vy_u32x4*>(d + A_XI + 2 * A_PL) = L;
+      }
     };
     auto compute = [&](const unsigned char* sa, const unsigned char* sw) {
 #pragma unroll
