@@ -601,7 +601,8 @@ def main():
                "speedup_over_exact": sfps / fps, "n_gpus": world,
                "workload": "the headline step (%dx%d, batch %d per GPU) with net.set_conv_mode('split_bf16x3'): every "
                            "conv+BN+leaky cell with cout %% 64 == 0 on v_mfma_f32_32x32x16_bf16 (six bf16 products per "
-                           "fp32 multiply, fp32 accumulate); stem, the 64->32 bottleneck, prediction convs, decode and NMS "
+                           "fp32 multiply, fp32 accumulate; the long-K 3x3 stride-1 cells as Winograd F(2, 3) on the same "
+                           "arithmetic, conv_wino.hip); stem, the 64->32 bottleneck, prediction convs, decode and NMS "
                            "as in the exact path.  Not bit-equal to the oracle: tests/test_gpu_split.py"
                            % (args.size, args.size, args.batch)}
         if rank == 0 and not args.no_roofline:
@@ -610,19 +611,25 @@ def main():
             ex = [a for k, a in sagg.items() if k.startswith("conv_igemm_kernel")]
             sp_ms, sp_fl = sum(a[1] for a in sp), sum(a[2] for a in sp)
             tot_ms, tot_fl = sum(a[1] for a in sagg.values()), sum(a[2] for a in sagg.values())
-            eq = sp_fl / (sp_ms * 1e-3) / 1e12  # fp32-equivalent TFLOP/s of the split launches
+            eq = sp_fl / (sp_ms * 1e-3) / 1e12  # fp32-equivalent TFLOP/s of the split launches (FLOPs of the DIRECT conv)
+            wino = [a for k, a in sagg.items() if k.startswith("conv_wino_kernel")]  # Winograd F(2, 3): 2/3 of the multiplications
+            issued = (sp_fl - sum(a[2] for a in wino) / 3.0) * SPLIT_PRODUCTS / (sp_ms * 1e-3) / 1e12
             leg["roofline"] = {
-                "bound": "mfma", "kernel": "conv_split_kernel (all instances)", "launches_per_step": sum(a[0] for a in sp),
+                "bound": "mfma", "kernel": "conv_split_kernel + conv_wino_kernel (all instances)",
+                "launches_per_step": sum(a[0] for a in sp),
                 "ms_per_step": sp_ms, "achieved_fp32_equivalent": eq, "unit": "TFLOP/s",
                 "frac_vs_fp32_mfma_peak_157": eq / FP32_MFMA_PEAK_TFLOPS,
                 "frac_vs_bf16_peak_over_6_419": eq / (BF16_MFMA_PEAK_TFLOPS / SPLIT_PRODUCTS),
-                "bf16_mfma_tflops": eq * SPLIT_PRODUCTS, "bf16_mfma_peak": BF16_MFMA_PEAK_TFLOPS,
+                "winograd_launches": sum(a[0] for a in wino), "winograd_ms": sum(a[1] for a in wino),
+                "winograd_note": "conv_wino.hip: the long-K 3x3 stride-1 cells as a 1-D Winograd F(2, 3) on the same split "
+                                 "arithmetic (2/3 of the multiplications); FLOPs above are the direct conv's",
+                "bf16_mfma_tflops": issued, "bf16_mfma_peak": BF16_MFMA_PEAK_TFLOPS,
                 "exact_kernel_launches_left": sum(a[0] for a in ex), "exact_kernel_ms_left": sum(a[1] for a in ex),
                 "whole_step_fp32_equivalent_tflops": tot_fl / (tot_ms * 1e-3) / 1e12,
                 "kernel_share_of_step_time": sp_ms / tot_ms,
                 "by_kernel_ms": {k: round(a[1], 4) for k, a in sagg.items()}, "traffic": None}
             if split_traffic:
-                keys = [k for k in split_traffic if k.startswith("void conv_split_kernel")]
+                keys = [k for k in split_traffic if k.startswith("void conv_split_kernel") or k.startswith("conv_wino_kernel")]
                 n_l = sum(split_traffic[k]["launches"] for k in keys)
                 if n_l:
                     hb = sum(split_traffic[k]["hbm_bytes"] * split_traffic[k]["launches"] for k in keys) / n_l
@@ -630,7 +637,7 @@ def main():
                     leg["roofline"]["traffic"] = hb
                     leg["roofline"]["traffic_detail"] = {
                         "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child runs with --conv-mode split_bf16x3 (FETCH x2: "
-                                  "gfx950); mean HBM bytes per conv_split_kernel launch",
+                                  "gfx950); mean HBM bytes per conv_split_kernel / conv_wino_kernel launch",
                         "algorithmic_bytes_per_launch_avg": alg, "over_algorithmic": hb / alg if alg else None,
                         "whole_step_hbm_bytes": split_traffic["_per_step"]}
             if leg["roofline"]["traffic"] is None:
