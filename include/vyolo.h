@@ -124,12 +124,14 @@ int vy_net_set_keep_activations(vy_net* net, int32_t keep);
  *   VY_CONV_SPLIT_BF16X3   opt-in, INFERENCE: every conv+BN+leaky cell with cout % 64 == 0 whose launch is large enough
  *                          (per-launch cost model) runs on the bf16 matrix core — every fp32 operand cut exactly into
  *                          three bf16 numbers, six partial products per multiply, fp32 accumulation
- *                          (csrc/conv_split.hip); NOT bit-equal to the exact path (tolerances:
- *                          tests/test_gpu_split.py), 1.3x the frames/s at 608x608 batch 64.  Planes, stem, prediction
- *                          convs, decode and NMS are shared with the exact path.  Training runs the exact kernels.
+ *                          (csrc/conv_split.hip); its long-K 3x3 stride-1 cells in big launches run the same
+ *                          arithmetic as a 1-D Winograd F(2, 3) (csrc/conv_wino.hip: a third fewer multiplications).
+ *                          NOT bit-equal to the exact path (tolerances: tests/test_gpu_split.py), 1.46x the frames/s at
+ *                          608x608 batch 64.  Planes, stem, prediction convs, decode and NMS are shared with the exact
+ *                          path.  Training runs the exact kernels.
  *   VY_CONV_SPLIT_BF16X3_TRAIN   as above, and TRAINING too: the recorded forward, the data gradients (conv_split.hip)
  *                          and the weight gradients of every conv with cout % 128 == 0 (wgrad_split.hip) on the bf16
- *                          matrix core; 1.13x the training frames/s at 416x416 batch 16.  Losses within 1e-4 of the exact
+ *                          matrix core; 1.15x the training frames/s at 416x416 batch 16.  Losses within 1e-4 of the exact
  *                          path; gradients as far from it as a one-ulp change of the input moves the exact path's own
  *                          (tests/test_gpu_split.py).
  * Changes the plan (the pre-split weight images live in the workspace): call before vy_net_workspace_bytes /
