@@ -8,9 +8,10 @@
 //     V_0 = d0 - d2   V_1 = d1 + d2   V_2 = d2 - d1   V_3 = d1 - d3
 //     U_0 = g0        U_1 = (g0 + g1 + g2) / 2        U_2 = (g0 - g1 + g2) / 2        U_3 = g2
 //     M_xi = sum over (dy, channel) of V_xi U_xi            Y(x0) = M_0 + M_1 + M_2      Y(x0 + 1) = M_1 - M_2 - M_3
-// — four GEMMs of K = 3 Cin instead of one of K = 9 Cin over half as many rows.  V is formed in registers from three
-// pixel loads of the row the A load touches anyway and cut into the three bf16 planes exactly as conv_split.hip cuts
-// its activations (x = h + m + l, six products per multiply); U is transformed in fp32 and cut ONCE per parameter change
+// — four GEMMs of K = 3 Cin instead of one of K = 9 Cin over half as many rows.  V is formed in registers from two
+// pixels of the row the A load touches anyway (one V per thread: waves 0-1 the first xi of a phase, waves 2-3 the second —
+// forming both in waves 0-1 from three loads left waves 2-3 idle while they cut: 2 % slower) and cut into the three bf16
+// planes exactly as conv_split.hip cuts its activations (x = h + m + l, six products per multiply); U is transformed in fp32 and cut ONCE per parameter change
 // into four tile images of the split kernel's format (wino_weights_kernel).  Rounding differs from the direct form
 // (sums of two inputs are rounded to fp32 before they are cut; the output transform adds three fp32 numbers): measured
 // against float64 it is as close as the exact fma chain (tools/probe/conv_wino_probe.hip: 1.7e-6 ... 5.4e-6).
@@ -18,7 +19,7 @@
 // Block = 64 pairs x 128 channels, 4 waves (32 pairs x 64 channels each), four accumulator sets per wave (128 registers),
 // two phases (xi = 0, 1 then 2, 3), TWO xi per k-step: 24 MFMAs per wave and barrier interval like the 128 x 128 tile of
 // conv_split.hip.  LDS: two stages of [2 xi][3 planes] for A (64 rows) and W (128 rows), 74 KB: two blocks per CU.  A
-// loads and W DMA run one k-step ahead; the wait before a barrier is counted (the A loads are younger than the DMA).
+// loads and W DMA run one k-step ahead; the wait before a barrier is counted (the four A loads are younger than the DMA).
 // Measured beside the 128 x 128 direct tile at 608x608 batch 64 (profiles/r04_wino_probe.txt): 76x76 128->256 +9 %,
 // 38x38 256->512 +16 %, 19x19 512->1024 +15 %; short-K (Cin = 64) and small launches lose and stay on conv_split.hip.
 #include <algorithm>
@@ -122,8 +123,9 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvArgs a, con
     r_off1[rr] = ok1 ? (rel + 1u) * (unsigned)a.r_cs * 4u : kInvalidRow;
   }
   __syncthreads();
-  const bool a_active = wave < 2;  // 64 rows x 2 octets = 128 staging threads
-  const int row_s = (tid & 127) >> 1, oct_s = tid & 1;
+  // A staging: 64 rows x 2 octets x 2 xi = 256 items, one per thread; waves 0-1 form the first xi of the phase's pair,
+  // waves 2-3 the second (each V needs two of the row's pixels: four 16-B loads, one cut, three ds_writes per thread)
+  const int row_s = (tid & 127) >> 1, oct_s = tid & 1, e_s = wave >> 1;
   const float* a_ptr = a.in + in_off[row_s] + oct_s * 8;
   // d3 of a pair without an x0 + 1 (odd width) would lie past the row's right border: it only feeds the discarded
   // Y(x0 + 1), so that row reads d1 again instead
@@ -152,7 +154,10 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvArgs a, con
 
   auto phase = [&](auto ph_) {
     constexpr int PH = decltype(ph_)::value;  // xi = 2 PH, 2 PH + 1;  pixels d0 d1 d2  |  d1 d2 d3
-    const int dxa = PH == 0 ? -a.a_cs : 0, dxb = PH == 0 ? 0 : a.a_cs, dxc = PH == 0 ? a.a_cs : dx3;
+    // V_0 = d0 - d2   V_1 = d1 + d2   V_2 = d2 - d1   V_3 = d1 - d3     (offsets of the minuend / first and the second pixel)
+    const int dxp = PH == 0 ? (e_s == 0 ? -a.a_cs : 0) : (e_s == 0 ? a.a_cs : 0);
+    const int dxq = PH == 0 ? a.a_cs : (e_s == 0 ? 0 : dx3);
+    const bool add = PH == 0 && e_s == 1;
     const unsigned char* w_tile0 =
         reinterpret_cast<const unsigned char*>(a.w_split) + (2 * PH) * wimg_bytes + (long long)(n0 >> 5) * KS * 3072;
     const unsigned char* w_tile1 = w_tile0 + wimg_bytes;
@@ -167,15 +172,12 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvArgs a, con
       w_koff = (long long)(w_tap * cch + w_cc) * 3072;
       if (++w_cc == cch) w_cc = 0, ++w_tap;
     };
-    f32x4 pa[2], pb[2], pc[2];
+    f32x4 pp[2], pq[2];
     auto load_a = [&]() {
-      if (!a_active) return;
-      const f32x4* x0 = reinterpret_cast<const f32x4*>(a_ptr + a_koff + dxa);
-      const f32x4* x1 = reinterpret_cast<const f32x4*>(a_ptr + a_koff + dxb);
-      const f32x4* x2 = reinterpret_cast<const f32x4*>(a_ptr + a_koff + dxc);
-      pa[0] = x0[0], pa[1] = x0[1];
-      pb[0] = x1[0], pb[1] = x1[1];
-      pc[0] = x2[0], pc[1] = x2[1];
+      const f32x4* x0 = reinterpret_cast<const f32x4*>(a_ptr + a_koff + dxp);
+      const f32x4* x1 = reinterpret_cast<const f32x4*>(a_ptr + a_koff + dxq);
+      pp[0] = x0[0], pp[1] = x0[1];
+      pq[0] = x1[0], pq[1] = x1[1];
     };
     auto dma_w = [&](int stage) {
 #pragma unroll
@@ -183,33 +185,18 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvArgs a, con
         lds_dma16_s(w_voff[j], reinterpret_cast<const float*>((j >= 3 ? w_tile1 : w_tile0) + w_koff), lds0 + stage * W_ST + w_lds[j]);
     };
     auto store_a = [&](int stage) {
-      if (!a_active) return;
+      f32x4 u0, u1;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        u0[e] = add ? pp[0][e] + pq[0][e] : pp[0][e] - pq[0][e];
+        u1[e] = add ? pp[1][e] + pq[1][e] : pp[1][e] - pq[1][e];
+      }
       vy_u32x4 H, M, L;
-      unsigned char* d = smem + stage * A_ST + a_lds;
-      {
-        f32x4 u0, u1;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          if (PH == 0) u0[e] = pa[0][e] - pc[0][e], u1[e] = pa[1][e] - pc[1][e];  // V0 = d0 - d2
-          else u0[e] = pb[0][e] - pa[0][e], u1[e] = pb[1][e] - pa[1][e];           // V2 = d2 - d1
-        }
-        split8(u0, u1, H, M, L);
-        *reinterpret_cast<vy_u32x4*>(d) = H;
-        *reinterpret_cast<vy_u32x4*>(d + A_PL) = M;
-        *reinterpret_cast<vy_u32x4*>(d + 2 * A_PL) = L;
-      }
-      {
-        f32x4 v0, v1;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          if (PH == 0) v0[e] = pb[0][e] + pc[0][e], v1[e] = pb[1][e] + pc[1][e];  // V1 = d1 + d2
-          else v0[e] = pa[0][e] - pc[0][e], v1[e] = pa[1][e] - pc[1][e];           // V3 = d1 - d3
-        }
-        split8(v0, v1, H, M, L);
-        *reinterpret_cast<vy_u32x4*>(d + A_XI) = H;
-        *reinterpret_cast<vy_u32x4*>(d + A_XI + A_PL) = M;
-        *reinterpret_cast<vy_u32x4*>(d + A_XI + 2 * A_PL) = L;
-      }
+      split8(u0, u1, H, M, L);
+      unsigned char* d = smem + stage * A_ST + e_s * A_XI + a_lds;
+      *reinterpret_cast<vy_u32x4*>(d) = H;
+      *reinterpret_cast<vy_u32x4*>(d + A_PL) = M;
+      *reinterpret_cast<vy_u32x4*>(d + 2 * A_PL) = L;
     };
     auto compute = [&](const unsigned char* sa, const unsigned char* sw) {
 #pragma unroll
@@ -248,8 +235,8 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvArgs a, con
         load_a();
       }
       compute(smem + ST * A_ST, smem + ST * W_ST);
-      if (HAS1) {  // this wave's W(t + 1) DMA must have landed before the next barrier; the six A(t + 2) loads are younger
-        if (HAS2 && a_active) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      if (HAS1) {  // this wave's W(t + 1) DMA must have landed before the next barrier; the four A(t + 2) loads are younger
+        if (HAS2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
     };
