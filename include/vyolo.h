@@ -126,7 +126,7 @@ int vy_net_set_keep_activations(vy_net* net, int32_t keep);
  *                          three bf16 numbers, six partial products per multiply, fp32 accumulation
  *                          (csrc/conv_split.hip); its long-K 3x3 stride-1 cells in big launches run the same
  *                          arithmetic as a 1-D Winograd F(2, 3) (csrc/conv_wino.hip: a third fewer multiplications).
- *                          NOT bit-equal to the exact path (tolerances: tests/test_gpu_split.py), 1.46x the frames/s at
+ *                          NOT bit-equal to the exact path (tolerances: tests/test_gpu_split.py), 1.5x the frames/s at
  *                          608x608 batch 64.  Planes, stem, prediction convs, decode and NMS are shared with the exact
  *                          path.  Training runs the exact kernels.
  *   VY_CONV_SPLIT_BF16X3_TRAIN   as above, and TRAINING too: the recorded forward, the data gradients (conv_split.hip)
