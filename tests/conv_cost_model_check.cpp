@@ -39,6 +39,14 @@ int main() {
       if (vy_predict_split(s.M, s.N, s.K, 1, &b1, &b2, &k1) < ts - 1e-9 || k1 != 1)
         return fprintf(stderr, "allowing k-split made the split prediction worse\n"), 1;
     }
+    // ... and whether its 3x3 stride-1 cell goes to the Winograd F(2, 3) instance instead (vy_conv_wino_pays: its model
+    // against 0.97 x the better of the other two; pairs = M / 2: even widths)
+    if (s.N % 128 == 0 && (long long)s.K % 288 == 0) {
+      int sbm = 0, sbn = 0, sks = 0;
+      const double ts = vy_predict_split(s.M, s.N, s.K, 64, &sbm, &sbn, &sks);
+      const double tw = vy_predict_wino(s.M / 2, s.N, (int)(s.K / 9));
+      printf(tw < 0.97 * (ts < t ? ts : t) ? "   | wino" : "   | -");
+    }
     printf("\n");
     if (sk0) return fprintf(stderr, "stream-K chosen although not allowed\n"), 1;
     if (t > t0 * (1.0 + 1e-12)) return fprintf(stderr, "allowing stream-K made the prediction worse\n"), 1;

@@ -233,9 +233,9 @@ def test_default_policy_keeps_small_launches_exact(voc_classes, synth20, monkeyp
     result obeys the bars."""
     monkeypatch.delenv("VY_SPLIT_ALWAYS")
     net = _net(voc_classes, synth20)
-    n1 = sum("|split" in n for n in _split_launches(net, frames(1, 416)))
+    n1 = sum("|split" in n or "|wino" in n for n in _split_launches(net, frames(1, 416)))
     x16 = frames(16, 416, seed=3)
-    n16 = sum("|split" in n for n in _split_launches(net, x16))
+    n16 = sum("|split" in n or "|wino" in n for n in _split_launches(net, x16))
     assert n1 < n16 and n1 <= 45 and n16 >= 50, (n1, n16)
     assert any("k" in n.split("|split")[1] for n in _split_launches(net, frames(1, 416)) if "|split" in n)   # split-K is in use
     net(x16[:2])

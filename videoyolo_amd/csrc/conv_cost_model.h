@@ -127,3 +127,17 @@ inline double vy_predict_split(long long M, int N, double K, int max_ksplit, int
   }
   return best;
 }
+
+// ---- the Winograd F(2, 3) instance of the split conv (conv_wino.hip: 64 pixel pairs x 128 channels per block, two blocks per
+// CU, no k-split) -----------------------------------------------------------------------------------------------------------
+// Fitted on tools/layer_profile.py with VY_SPLIT_WINO=2 / 0 at 608x608 and 416x416, batch 1 ... 64: a block alone on its CU
+// takes 0.40 us per input channel + 10 (launch included); two resident blocks 0.62 us per channel + 7 together, a launch of
+// more than 256 blocks that many rounds of 512 (whole rounds up to four, then the fraction: the tail of a long launch
+// overlaps).  Kc = input channels (the four GEMMs' K is 3 Kc each).
+inline double vy_predict_wino(long long pairs, int N, int Kc) {
+  const long long blocks = ((pairs + 63) / 64) * (N / 128);
+  if (blocks <= 256) return 0.40 * Kc + 10.0;
+  if (blocks <= 1024) return (double)((blocks + 511) / 512) * (0.55 * Kc + 6.0) + 4.0;  // (short launches: the chip is not yet held by its power cap)
+  const double rounds = blocks <= 2048 ? (double)((blocks + 511) / 512) : (double)blocks / 512.0;
+  return rounds * (0.62 * Kc + 7.0) + 4.0;
+}

@@ -21,7 +21,8 @@
 // conv_split.hip.  LDS: two stages of [2 xi][3 planes] for A (64 rows) and W (128 rows), 74 KB: two blocks per CU.  A
 // loads and W DMA run one k-step ahead; the wait before a barrier is counted (the four A loads are younger than the DMA).
 // Measured beside the 128 x 128 direct tile at 608x608 batch 64 (profiles/r04_wino_probe.txt): 76x76 128->256 +9 %,
-// 38x38 256->512 +16 %, 19x19 512->1024 +15 %; short-K (Cin = 64) and small launches lose and stay on conv_split.hip.
+// 38x38 256->512 +16 %, 19x19 512->1024 +15 %; in the net (tools/layer_profile.py, VY_SPLIT_WINO=2 / 0) every supported cell
+// wins from batch 8 on, none of a single frame's (those stay on conv_split.hip's k-split): vy_conv_wino_pays.
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
@@ -30,6 +31,7 @@
 #include "kernels.h"
 #include "../../include/vy_math.h"
 #include "split_device.h"
+#include "conv_cost_model.h"
 
 // weights [cout][3][3][cin] fp32 -> four images (xi) of [cout / 32][3 cin / 16][plane][32 rows][2 slots][8 channels]
 __global__ void wino_weights_kernel(const float* __restrict__ w, unsigned short* __restrict__ img, const int cout, const int cin,
@@ -331,15 +333,24 @@ static long long wino_tiles(const ConvArgs& a) {
   return ((pairs + 63) / 64) * (a.N / 128);
 }
 
-// Where it beats the direct split tile (profiles/r04_wino_probe.txt): K = 9 Cin >= 1152 and a launch of several rounds of
-// blocks; VY_SPLIT_WINO=0: never, =2: wherever supported (tests)
+// Per launch, where the cost models say it wins (conv_cost_model.h: vy_predict_wino against the split kernel's and the
+// exact kernel's predictions): at 608x608 every supported cell from batch 8 on, the 152x152 / 76x76 ones from batch 2, none of
+// a single frame's (the split kernel's k-split covers those).  VY_SPLIT_WINO=0: never, =2: wherever supported (tests)
 bool vy_conv_wino_pays(const ConvArgs& a) {
   if (!vy_conv_wino_supported(a)) return false;
   const char* sw = getenv("VY_SPLIT_WINO");  // read per call (tests switch it)
   const int mode = sw ? atoi(sw) : 1;
   if (mode == 0) return false;
   if (mode == 2) return true;
-  return a.Kc >= 128 && wino_tiles(a) >= 1024;
+  const long long pairs = (long long)a.B * a.LH * ((a.LW + 1) / 2);
+  const double t_wino = vy_predict_wino(pairs, a.N, a.Kc);
+  double t_other = vy_conv_predict_us(a);
+  if (vy_conv_split_supported(a)) {
+    const long long max_ks = a.splitk_slabs ? std::max<long long>(1, (long long)(a.splitk_bytes / ((unsigned long long)a.M * a.N * 4ull))) : 1;
+    int bm, bn, ks;
+    t_other = std::min(t_other, vy_predict_split(a.M, a.N, 9.0 * a.Kc, (int)std::min<long long>(max_ks, 64), &bm, &bn, &ks));
+  }
+  return t_wino < 0.97 * t_other;
 }
 
 hipError_t vy_launch_conv_wino(const ConvArgs& a, hipStream_t s) {

@@ -101,7 +101,7 @@ hipError_t vy_launch_split_weights_batch(const float* params, void* ws, const Sp
 size_t vy_wino_weight_bytes(int cout, int cin);
 hipError_t vy_launch_wino_weights(const float* w, void* img, int cout, int cin, hipStream_t s);
 bool vy_conv_wino_supported(const ConvArgs& a);
-bool vy_conv_wino_pays(const ConvArgs& a);          // K = 9 Cin >= 1152 and a launch of >= 1024 blocks; VY_SPLIT_WINO=0 / 2
+bool vy_conv_wino_pays(const ConvArgs& a);          // the cost models' verdict (conv_cost_model.h: vy_predict_wino); VY_SPLIT_WINO=0 / 2
 hipError_t vy_launch_conv_wino(const ConvArgs& a, hipStream_t s);
 bool vy_conv_split_supported(const ConvArgs& a);   // forward, N % 64 == 0, Kc % 32 == 0, an epilogue the kernel has
 void vy_conv_split_cfg(const ConvArgs& a, int* bm, int* bn, int* ksplit);  // block tile and k-split the launch will use
