@@ -156,6 +156,19 @@ def measure_hbm_traffic(argv, steps_run):
 SPLIT_DTYPE = "f32 via bf16x3 (6 products), f32 acc"
 
 
+_JSON_FD = None
+
+
+def _emit(result):
+    """the one line of the contract, on the process's REAL stdout (main() points fd 1 at stderr: library chatter)"""
+    line = (json.dumps(result) + "\n").encode()
+    sys.stdout.flush()
+    if _JSON_FD is None:
+        os.write(1, line)
+    else:
+        os.write(_JSON_FD, line)
+
+
 def launch_table(net, x):
     """Median-of-3 per-launch table of one forward: [(name, ms, flops, algorithmic bytes)] (HIP events around every
     launch, on the launch stream) and the same aggregated per kernel instance {key: [launches, ms, flops, bytes]}."""
@@ -420,6 +433,14 @@ def main():
     from videoyolo_amd import launch
     if launch.needs_spawn(args.gpus):
         sys.exit(launch.spawn_ranks(args.gpus, [os.path.abspath(__file__)] + sys.argv[1:]))
+    # From here on this process is a rank (or the single process of N = 1).  The contract is ONE JSON line on stdout:
+    # libraries write there too (gloo announces "[Gloo] Rank 0 is connected to ..." on stdout when a group is created —
+    # also the host side group beside RCCL), so file descriptor 1 is pointed at stderr for the rest of the run and the
+    # line goes out through a saved copy of the real stdout.
+    global _JSON_FD
+    sys.stdout.flush()
+    _JSON_FD = os.dup(1)
+    os.dup2(2, 1)
     if args.mode == "train":
         if "--size" not in " ".join(sys.argv):
             args.size = 416
@@ -726,7 +747,7 @@ def main():
             result["also_syncbn608"] = leg
 
     if rank == 0:
-        print(json.dumps(result))
+        _emit(result)
     if dist is not None:
         dist.barrier()  # rank 0 may still be in its un-timed measurement passes: leave together
         dist.destroy_process_group()
@@ -776,7 +797,7 @@ def bench_train(args, vy, dev, dist, rank, world, traffic=None, traffic_note=Non
         else:
             result["roofline"]["traffic_note"] = traffic_note
     if rank == 0:
-        print(json.dumps(result))
+        _emit(result)
     if dist is not None:
         dist.barrier()  # rank 0 may still be in its un-timed measurement passes: leave together
         dist.destroy_process_group()

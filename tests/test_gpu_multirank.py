@@ -187,8 +187,8 @@ def test_bench_starts_its_own_ranks(extra):
            "--train-steps", "2", "--no-split-leg"] + extra   # (the split legs at 2 ranks: test_bench_under_torch_distributed_run)
     p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
     assert p.returncode == 0, p.stderr.decode()[-2000:]
-    lines = [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
-    assert len(lines) == 1, p.stdout.decode()
+    lines = p.stdout.decode().splitlines()
+    assert len(lines) == 1 and lines[0].startswith("{"), p.stdout.decode()   # ONE line on stdout: gloo's "[Gloo] Rank 0 is connected ..." goes to stderr
     r = json.loads(lines[0])
     assert r["n_gpus"] == 2 and r["config"]["global_batch"] == 4 and r["value"] > 0
     assert r["scaling"] == "weak" and r["steps"] == 2
@@ -222,8 +222,8 @@ def test_bench_under_torch_distributed_run():
            "--train-size", "64", "--train-batch", "2", "--syncbn-size", "96", "--syncbn-batch", "2", "--train-steps", "2"]
     p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
     assert p.returncode == 0, p.stderr.decode()[-2000:]
-    lines = [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
-    assert len(lines) == 1, p.stdout.decode()
+    lines = p.stdout.decode().splitlines()
+    assert len(lines) == 1 and lines[0].startswith("{"), p.stdout.decode()   # exactly the one line of the contract
     r = json.loads(lines[0])
     assert r["n_gpus"] == 2 and r["config"]["global_batch"] == 4 and r["value"] > 0 and r["scaling"] == "weak"
     for leg in ("also_infer96_split", "also_train416", "also_train416_split", "also_syncbn608"):
