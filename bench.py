@@ -39,6 +39,10 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# under the driver's `python -m torch.distributed.run ... bench.py` the ranks are NOT started by videoyolo_amd.launch:
+# RCCL across processes needs dmabuf IPC on this host driver, and the HSA runtime reads this when the first GPU call
+# initialises it — set it before torch is imported
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs @ 2.4 GHz
 BF16_MFMA_PEAK_TFLOPS = 2516.6  # v_mfma_f32_32x32x16_bf16: 16x the fp32 rate (same guide); the split path spends

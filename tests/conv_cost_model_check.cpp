@@ -62,5 +62,30 @@ int main() {
       if (plain - t < 0.03 * plain - 1e-9) return fprintf(stderr, "stream-K below its threshold\n"), 1;
     }
   }
+  // ---- another chip: the models count their rounds in the device's CU count, and every choice
+  // BETWEEN kernels is refused where the constants were not fitted.  128 CUs = the MI355X in DPX mode.
+  if (!vy_model_fitted(256) || vy_model_fitted(128) || vy_model_fitted(64) || vy_model_fitted(304))
+    return fprintf(stderr, "vy_model_fitted must hold for 256 CUs only\n"), 1;
+  printf("-- 128 CUs\n");
+  for (const Shape& s : shapes) {
+    int bm = 0, bn = 0, b2 = 0, n2 = 0;
+    bool sk = false, sk2 = false;
+    const double t128 = vy_select_tile(s.M, s.N, s.K, off, &bm, &bn, &sk, 128);
+    const double t256 = vy_select_tile(s.M, s.N, s.K, off, &b2, &n2, &sk2, 256);
+    printf("%lld %d %.0f -> %dx%d\n", s.M, s.N, s.K, bm, bn);
+    if (s.N > 32 && t128 < t256 * (1.0 - 1e-12)) return fprintf(stderr, "half the CUs predicted faster\n"), 1;
+    // a launch that fills 256 CUs for many rounds takes twice as long on 128
+    const long long tiles = ((s.M + bm - 1) / bm) * ((s.N + bn - 1) / bn);
+    if (s.N > 32 && tiles >= 64 * 256 && bm == b2 && bn == n2 && (t128 < 1.9 * t256 || t128 > 2.1 * t256))
+      return fprintf(stderr, "a long launch must scale with the CU count (%.1f vs %.1f)\n", t128, t256), 1;
+    if (s.N % 64 == 0) {
+      int sbm, sbn, sks;
+      const double a = vy_predict_split(s.M, s.N, s.K, 64, &sbm, &sbn, &sks, 128), b = vy_predict_split(s.M, s.N, s.K, 64, &sbm, &sbn, &sks, 256);
+      if (a < b * (1.0 - 1e-12)) return fprintf(stderr, "split model: half the CUs predicted faster\n"), 1;
+    }
+    if (s.N % 128 == 0 && (long long)s.K % 288 == 0 &&
+        vy_predict_wino(s.M / 2, s.N, (int)(s.K / 9), 128) < vy_predict_wino(s.M / 2, s.N, (int)(s.K / 9), 256) * (1.0 - 1e-12))
+      return fprintf(stderr, "Winograd model: half the CUs predicted faster\n"), 1;
+  }
   return 0;
 }

@@ -99,3 +99,27 @@ def test_traffic_is_skipped_inside_a_profiler(monkeypatch, tmp_path):
     monkeypatch.setenv("ROCP_TOOL_LIBRARIES", "/opt/rocm/lib/librocprofiler-sdk-tool.so")
     out, note = bench.measure_hbm_traffic(["--steps", "1"], steps_run=2)
     assert out is None and "profiled" in note
+
+
+def test_ipc_mode_is_set_before_torch_whatever_the_launcher():
+    """HSA_ENABLE_IPC_MODE_LEGACY=0 (dmabuf IPC; RCCL across processes needs it on this host driver)
+    used to be set only by the repo's own launcher — a rank started by `python -m torch.distributed.run bench.py` never
+    had it.  bench.py and the package now set it themselves, before torch is imported (the HSA runtime reads it when the
+    first GPU call initialises it)."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k != "HSA_ENABLE_IPC_MODE_LEGACY"}
+    code = ("import sys, os; sys.path.insert(0, %r)\n"
+            "import %s\n"
+            "assert os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY') == '0', 'not set'\n"
+            "print('torch' in sys.modules)")
+    for mod in ("bench", "videoyolo_amd"):
+        p = subprocess.run([sys.executable, "-c", code % (ROOT, mod)], env=env, capture_output=True, text=True, timeout=300)
+        assert p.returncode == 0, p.stderr
+    # bench.py: set at module level, before anything could have imported torch
+    p = subprocess.run([sys.executable, "-c", code % (ROOT, "bench")], env=env, capture_output=True, text=True, timeout=300)
+    assert p.stdout.strip() == "False", "importing bench.py pulled torch in before main(): the setdefault must stay ahead of it"
+    # an explicit setting of the caller wins
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "1"
+    p = subprocess.run([sys.executable, "-c", "import sys, os; sys.path.insert(0, %r); import bench; print(os.environ['HSA_ENABLE_IPC_MODE_LEGACY'])" % ROOT],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert p.stdout.strip() == "1"

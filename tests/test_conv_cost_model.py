@@ -9,7 +9,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # M N K -> tile of the exact kernel | conv mode split_bf16x3: the kernel the launch goes to (round 4;
 # profiles/r04_layers_608_b64_split.txt, tools/probe/run_split_batch_sweep.sh, run_split_ksplit_sweep.sh):
 # 608x608 batch 64, then 416x416 batch 16 (training forward shapes), then batch 1; third column: 3x3 cells the Winograd
-# F(2, 3) instance takes instead (conv_wino.hip, vy_predict_wino; fitted on tools/layer_profile.py sweeps)
+# F(2, 3) instance takes instead (conv_wino.hip, vy_predict_wino; fitted on tools/layer_profile.py sweeps).
+# After "-- 128 CUs": the exact kernel's tiles on a device of 128 CUs (the models count rounds in the device's CU count;
+# the split / Winograd choices are refused there: vy_model_fitted, checked by the program itself)
 EXPECTED = """\
 5914624 64 288 -> 128x64   | split 256x64
 5914624 32 64 -> 128x32
@@ -29,6 +31,25 @@ EXPECTED = """\
 43264 128 256 -> 128x64   | split 128x64
 5776 256 1152 -> 64x64   | split 128x128 k5   | -
 361 1024 4608 -> 64x64   | split 128x128 k10   | -
+-- 128 CUs
+5914624 64 288 -> 128x64
+5914624 32 64 -> 128x32
+1478656 128 576 -> 128x128
+1478656 64 128 -> 128x64
+369664 256 1152 -> 128x128
+369664 128 256 -> 128x128
+92416 512 2304 -> 128x128
+92416 256 512 -> 128x64
+23104 1024 4608 -> 128x64
+23104 512 1024 -> 128x128
+23104 75 1024 -> 128x64
+43264 256 1152 -> 128x64
+10816 512 2304 -> 64x64
+2704 1024 4608 -> 128x64
+2704 512 1024 -> 64x64
+43264 128 256 -> 128x128
+5776 256 1152 -> 64x64
+361 1024 4608 -> 64x64
 """
 
 

@@ -433,6 +433,29 @@ def test_split_training_equals_exact_training_when_switched_off(voc_classes, syn
     assert not np.array_equal(ga, gb)       # the split step really was a different summation
 
 
+def test_recorded_forward_then_inference_keeps_the_winograd_images(voc_classes, monkeypatch):
+    """in conv mode 'split_bf16x3_train' the recorded forward rebuilds the forward / data-gradient images in
+    one launch (train.hip: refresh_split_images) and used to clear the flag that also gates the Winograd image sets, which
+    only the inference forward rebuilds — a recorded forward followed by `net(x)` with no parameter write in between
+    (validation under record, gradient accumulation) then ran conv_wino_kernel on images that were never written.  The
+    Winograd sets have their own flag now (net_internal.h: wino_dirty).  Same plan for both calls (model.py reuses a
+    training plan for inference at the same size); every supported cell forced through the Winograd kernel."""
+    monkeypatch.setenv("VY_SPLIT_WINO", "2")
+    C, B, S = 20, 2, 128
+    params, x, gt_boxes, tg = _train_case(C, B, S)
+    net = _net(voc_classes, params, mode="split_bf16x3_train")
+    _step(net, x, gt_boxes, tg)                      # recorded forward + backward; no optimizer step
+    assert any("wino" in n for n in _split_launches(net, x)), "no Winograd launch in the inference pass"
+    got = [t.cpu().numpy() for t in net(x, return_index=True)]
+    heads = [net.read_head(i).cpu().numpy() for i in range(3)]
+    fresh = _net(voc_classes, params, mode="split_bf16x3")
+    want = [t.cpu().numpy() for t in fresh(x, return_index=True)]
+    for i in range(3):
+        assert np.array_equal(heads[i], fresh.read_head(i).cpu().numpy()), "head %d differs after a recorded forward" % i
+    for u, v in zip(got, want):
+        assert np.array_equal(u, v)
+
+
 @pytest.mark.parametrize("ncls,batch,obj_bias", [(20, 64, 0.0), (30, 32, -4.0)])
 def test_split_inference_full_size(ncls, batch, obj_bias, monkeypatch, capsys):
     """BASELINE configs[1] / configs[3] shapes (608 x 608, batch 64 / 30 classes batch 32) in the split conv mode under the

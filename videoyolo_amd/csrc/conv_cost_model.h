@@ -12,9 +12,21 @@
 // sk_schedule.h) takes T / 256 rounds, not rounded up, plus one hand-off: 7.5 us fitted on the short-K launches, which
 // lose exactly that.  (A two-wave 64x32 tile was tried for the 13x13 maps at batch 16, which are short of blocks: 461 vs
 // 337 us on the K = 9216 data gradients.)
+//
+// The chip.  Every constant below was fitted on the MI355X in SPX mode: 256 CUs.  The models take the CU count of the
+// device the launch goes to (`cus`: vy_cu_count(), hipDeviceAttributeMultiprocessorCount) and count their rounds in it —
+// a round is what ONE CU does with its share, which does not depend on how many CUs there are.  What does depend on the
+// chip is every comparison BETWEEN kernels (the split and Winograd instances were fitted against the exact kernel under
+// this part's power cap and L2 / LDS-DMA rates): vy_model_fitted(cus) is false for any other count, and the callers then
+// stay on the exact kernel's own tile model (vy_conv_split_pays / vy_conv_wino_pays refuse, as stream-K does through
+// vy_sk_verify_topology) — a partition mode (DPX 128, QPX 64, CPX 32 CUs) or a CU-masked queue gets correct, unsurprising
+// launches instead of choices that silently refer to a different chip.
 #pragma once
 
 #include <algorithm>
+
+#define VY_MODEL_CUS 256
+inline bool vy_model_fitted(int cus) { return cus == VY_MODEL_CUS; }
 
 struct VyTileModel {
   int bm, bn;
@@ -36,7 +48,8 @@ struct VySkPolicy {
 };
 
 // predicted time (microseconds) of a launch of M x N outputs with reduction length K on tile t; *use_sk: as stream-K
-inline double vy_predict_launch(long long M, int N, double K, const VyTileModel& t, const VySkPolicy& p, bool* use_sk) {
+inline double vy_predict_launch(long long M, int N, double K, const VyTileModel& t, const VySkPolicy& p, bool* use_sk,
+                                int cus = VY_MODEL_CUS) {
   const long long tiles = ((M + t.bm - 1) / t.bm) * ((N + t.bn - 1) / t.bn);
   const double t_round = t.alpha * K + t.fixed;
   // a block that has a CU to itself (one wave per SIMD) runs over the model: nobody covers its LDS-DMA latency.  Small
@@ -44,13 +57,13 @@ inline double vy_predict_launch(long long M, int N, double K, const VyTileModel&
   // tools/probe/conv_tile_trace.hip; the 26x26 training layers: 195 us as 128x128 stream-K with one block per CU against
   // 182 us as 128x64 stream-K with two)
   const double lone = t.bm * t.bn < 128 * 128 ? 1.12 : 1.25;
-  double t_plain = (double)((tiles + 255) / 256) * t_round;
-  if (tiles < 256) t_plain *= lone;
+  double t_plain = (double)((tiles + cus - 1) / cus) * t_round;
+  if (tiles < cus) t_plain *= lone;
   *use_sk = false;
-  if (p.allowed && tiles > 256) {
-    const long long per_cu = std::min<long long>(t.resident, tiles / 256);  // a share is at least one tile
-    if (tiles > 256 * per_cu) {
-      double t_sk = (double)tiles / 256.0 * t_round;
+  if (p.allowed && tiles > cus) {
+    const long long per_cu = std::min<long long>(t.resident, tiles / cus);  // a share is at least one tile
+    if (tiles > cus * per_cu) {
+      double t_sk = (double)tiles / (double)cus * t_round;
       if (per_cu == 1) t_sk *= lone;
       t_sk += p.cost;
       if (t_plain - t_sk >= p.min_gain * t_plain) {
@@ -63,7 +76,8 @@ inline double vy_predict_launch(long long M, int N, double K, const VyTileModel&
 }
 
 // the block tile with the smallest predicted time (a smaller tile has to be better by 0.5 %); N <= 32 has its own tile
-inline double vy_select_tile(long long M, int N, double K, const VySkPolicy& p, int* bm, int* bn, bool* use_sk) {
+inline double vy_select_tile(long long M, int N, double K, const VySkPolicy& p, int* bm, int* bn, bool* use_sk,
+                             int cus = VY_MODEL_CUS) {
   if (N <= 32) {
     *bm = 128, *bn = 32, *use_sk = false;
     return 0.0;
@@ -72,7 +86,7 @@ inline double vy_select_tile(long long M, int N, double K, const VySkPolicy& p, 
   for (const VyTileModel& c : kVyTileModels) {
     if (c.bn == 128 && N <= 64) continue;
     bool sk;
-    const double t = vy_predict_launch(M, N, K, c, p, &sk);  // as a plain or a stream-K launch, whichever will be used
+    const double t = vy_predict_launch(M, N, K, c, p, &sk, cus);  // as a plain or a stream-K launch, whichever will be used
     if (t < best * 0.995) {
       best = t;
       *bm = c.bm;
@@ -102,7 +116,7 @@ static const VySplitModel kVySplitModels[3] = {{128, 128, 0.0372, 3.0, 1.10}, {1
 // Fitted on tools/probe/run_split_ksplit_sweep.sh: the second launch, the slab round trip and the short k-loops'
 // pipeline fill cost about 9 us (19x19, K = 4608, one frame: 190 us unsplit, 36.7 us as 8 slices; the exact kernel 75 us);
 // every launch carries 4 us of fill / drain (a single frame's 152x152 layers: 38.6 us on 181 lone blocks, the exact kernel 34.3).
-inline double vy_predict_split(long long M, int N, double K, int max_ksplit, int* bm, int* bn, int* ksplit) {
+inline double vy_predict_split(long long M, int N, double K, int max_ksplit, int* bm, int* bn, int* ksplit, int cus = VY_MODEL_CUS) {
   double best = 1e300;
   *ksplit = 1;
   for (const VySplitModel& c : kVySplitModels) {
@@ -111,10 +125,10 @@ inline double vy_predict_split(long long M, int N, double K, int max_ksplit, int
     const long long tiles = ((M + c.bm - 1) / c.bm) * (N / c.bn);
     const int steps = (int)(K / 16.0);
     for (int S = 1; S <= max_ksplit && S <= 32; ++S) {
-      if (S > 1 && (tiles * (S - 1) >= 512 || steps / S < 6)) break;  // only while CUs have room and slices stay long enough
+      if (S > 1 && (tiles * (S - 1) >= 2 * cus || steps / S < 6)) break;  // only while CUs have room and slices stay long enough
       const long long blocks = tiles * S;
-      double t = (double)((blocks + 255) / 256) * (c.alpha * K / S + c.fixed);
-      if (blocks <= 256) t *= c.lone;
+      double t = (double)((blocks + cus - 1) / cus) * (c.alpha * K / S + c.fixed);
+      if (blocks <= cus) t *= c.lone;
       t += 4.0;               // per launch: pipeline fill and drain of a kernel that prefetches two k-steps ahead
       if (S > 1) t += 5.0;    // the finish launch and the slab round trip
       if (t < best * 0.995) {
@@ -134,10 +148,10 @@ inline double vy_predict_split(long long M, int N, double K, int max_ksplit, int
 // takes 0.40 us per input channel + 10 (launch included); two resident blocks 0.62 us per channel + 7 together, a launch of
 // more than 256 blocks that many rounds of 512 (whole rounds up to four, then the fraction: the tail of a long launch
 // overlaps).  Kc = input channels (the four GEMMs' K is 3 Kc each).
-inline double vy_predict_wino(long long pairs, int N, int Kc) {
-  const long long blocks = ((pairs + 63) / 64) * (N / 128);
-  if (blocks <= 256) return 0.40 * Kc + 10.0;
-  if (blocks <= 1024) return (double)((blocks + 511) / 512) * (0.55 * Kc + 6.0) + 4.0;  // (short launches: the chip is not yet held by its power cap)
-  const double rounds = blocks <= 2048 ? (double)((blocks + 511) / 512) : (double)blocks / 512.0;
+inline double vy_predict_wino(long long pairs, int N, int Kc, int cus = VY_MODEL_CUS) {
+  const long long blocks = ((pairs + 63) / 64) * (N / 128), pair_round = 2ll * cus;  // two resident blocks per CU
+  if (blocks <= cus) return 0.40 * Kc + 10.0;
+  if (blocks <= 2 * pair_round) return (double)((blocks + pair_round - 1) / pair_round) * (0.55 * Kc + 6.0) + 4.0;  // (short launches: the chip is not yet held by its power cap)
+  const double rounds = blocks <= 4 * pair_round ? (double)((blocks + pair_round - 1) / pair_round) : (double)blocks / (double)pair_round;
   return rounds * (0.62 * Kc + 7.0) + 4.0;
 }

@@ -633,15 +633,22 @@ static int resident_blocks(K kernel, int threads) {
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, threads, 0) != hipSuccess || n < 1) n = 1;
   return n;
 }
-static int cu_count() {
-  static int n = [] {
-    int dev = 0, c = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || c < 1)
-      c = 256;
-    return c;
-  }();
-  return n;
+// CUs of the current device (per device, queried once each; VY_CU_COUNT=n overrides it: tests of the cost models'
+// behaviour on a chip they were not fitted on).  256 when there is no device to ask (host-only callers)
+int vy_cu_count() {
+  static const int forced = getenv("VY_CU_COUNT") ? atoi(getenv("VY_CU_COUNT")) : 0;
+  if (forced > 0) return forced;
+  static int cache[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return VY_MODEL_CUS;
+  if (!cache[dev]) {
+    int c = 0;
+    if (hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || c < 1) c = VY_MODEL_CUS;
+    cache[dev] = c;
+  }
+  return cache[dev];
 }
+static int cu_count() { return vy_cu_count(); }
 
 // ---- stream-K topology check --------------------------------------------------------------------------------------
 // The stream-K schedule (sk_schedule.h) is built for the MI355X in SPX mode: 256 CUs, 8 XCDs, workgroups dealt round-robin
@@ -726,7 +733,7 @@ static hipError_t launch_cfg(const ConvArgs& a, hipStream_t s, bool* sk_query = 
     const long long G = sk_slots > 0 ? sk_slots : (long long)cus * per_cu;
     bool pays = false;
     if (const VyTileModel* tm = vy_tile_model(BM, BN))
-      vy_predict_launch(a.M, a.N, (double)a.ntaps * a.Kc, *tm, sk_policy(a), &pays);
+      vy_predict_launch(a.M, a.N, (double)a.ntaps * a.Kc, *tm, sk_policy(a), &pays, cus);
     if (G > 0 && tiles > G && tiles * (G + 8) < (1ll << 31) && 2 * (G / 8 + 1) * (long long)(a.ntaps * (a.Kc >> 5)) < (1ll << 31) &&
         (sk_slots > 0 || pays) && G * BM * BN * 4ll <= (long long)a.sk_bytes && G <= a.sk_nflags) {
       if (sk_query) {
@@ -771,7 +778,7 @@ static void select_cfg(const ConvArgs& a, int* bm, int* bn) {
   }
   const double K = (double)a.ntaps * a.Kc;
   bool sk_unused;
-  double best = vy_select_tile(a.M, a.N, K, sk_policy(a), bm, bn, &sk_unused);
+  double best = vy_select_tile(a.M, a.N, K, sk_policy(a), bm, bn, &sk_unused, cu_count());
   // 16x16 wave tiles (conv_small.hip; block tile 32 x {32, 64}): OFF by default.  Measured on the MI355X (round 3,
   // profiles/r03_negative_results.txt): bit-exact, but 1.9 - 2.0x SLOWER than the 64x64 tile on the batch-1 3x3 layers it
   // was built for (76x76: 78-85 vs 42 us, 38x38: 85-88 vs 43, 19x19: 98-128 vs 77) — a 32-channel sub-step of a 32x32
@@ -803,7 +810,7 @@ double vy_conv_predict_us(const ConvArgs& a) {
   if (a.N <= 32) return 0.0;  // own tile, no model: never handed to the split kernel (cout % 64 != 0 anyway)
   int bm, bn;
   bool sk;
-  return vy_select_tile(a.M, a.N, (double)a.ntaps * a.Kc, sk_policy(a), &bm, &bn, &sk);
+  return vy_select_tile(a.M, a.N, (double)a.ntaps * a.Kc, sk_policy(a), &bm, &bn, &sk, cu_count());
 }
 
 int vy_conv_tiles_m(const ConvArgs& a) {

@@ -638,15 +638,17 @@ void vy_conv_split_cfg(const ConvArgs& a, int* bm, int* bn, int* ksplit) {
     *ksplit = (int)std::min<long long>(std::max(1, fks), split_max_ksplit(a));
     return;
   }
-  vy_predict_split(a.M, a.N, (double)a.ntaps * a.Kc, (int)std::min<long long>(split_max_ksplit(a), 64), bm, bn, ksplit);
+  vy_predict_split(a.M, a.N, (double)a.ntaps * a.Kc, (int)std::min<long long>(split_max_ksplit(a), 64), bm, bn, ksplit, vy_cu_count());
 }
 
 bool vy_conv_split_pays(const ConvArgs& a) {
   if (!vy_conv_split_supported(a)) return false;
   const char* always = getenv("VY_SPLIT_ALWAYS");  // tests: every supported launch, however small (read per call)
   if (always && atoi(always)) return true;
+  const int cus = vy_cu_count();
+  if (!vy_model_fitted(cus)) return false;  // the comparison between the two kernels was fitted on 256 CUs (conv_cost_model.h)
   int bm, bn, ks;
-  return vy_predict_split(a.M, a.N, (double)a.ntaps * a.Kc, (int)std::min<long long>(split_max_ksplit(a), 64), &bm, &bn, &ks) <
+  return vy_predict_split(a.M, a.N, (double)a.ntaps * a.Kc, (int)std::min<long long>(split_max_ksplit(a), 64), &bm, &bn, &ks, cus) <
          0.97 * vy_conv_predict_us(a);
 }
 

@@ -78,10 +78,19 @@ hipError_t vy_launch_wino_weights(const float* w, void* img, int cout, int cin, 
   return hipGetLastError();
 }
 
-__global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvArgs a, const int tiles_n, const int Wp2, const int Mp,
-                                                           const long long wimg_bytes) {
+// probe builds only (tools/probe/wino_abl_probe.hip): what each part of the k-loop costs.  Bits: 1 no A loads, 2 no cut,
+// 4 no W DMA, 8 no MFMA, 16 no fragment reads.  Results are garbage with any bit set
+#ifndef VY_WINO_ABL
+#define VY_WINO_ABL 0
+#endif
+
+// BM = pairs per block: 64 (4 waves, two blocks per CU) or 128 (8 waves, one block per CU: a W tile feeds twice the rows —
+// half the LDS-DMA instructions and L2 bytes per MFMA)
+template <int BM>
+__global__ __launch_bounds__(BM * 4, BM == 64 ? 2 : 1) void conv_wino_kernel(const ConvArgs a, const int tiles_n, const int Wp2,
+                                                                              const int Mp, const long long wimg_bytes) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  constexpr int BM = 64, BN = 128, WN = 2, NW = 4, NT = 256;
+  constexpr int BN = 128, WN = 2, NW = BM / 16, NT = NW * 64, WJ = 24 / NW;
   constexpr int A_PL = BM * 32, W_PL = BN * 32, A_XI = 3 * A_PL, W_XI = 3 * W_PL, A_ST = 2 * A_XI, W_ST = 2 * W_XI;
   constexpr int W_BASE = 2 * A_ST;
   constexpr int TNs = 2;  // wave tile: 32 pairs x 64 channels
@@ -127,20 +136,22 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvArgs a, con
   __syncthreads();
   // A staging: 64 rows x 2 octets x 2 xi = 256 items, one per thread; waves 0-1 form the first xi of the phase's pair,
   // waves 2-3 the second (each V needs two of the row's pixels: four 16-B loads, one cut, three ds_writes per thread)
-  const int row_s = (tid & 127) >> 1, oct_s = tid & 1, e_s = wave >> 1;
+  const int row_s = (tid & (NT / 2 - 1)) >> 1, oct_s = tid & 1, e_s = wave / (NW / 2);
   const float* a_ptr = a.in + in_off[row_s] + oct_s * 8;
   // d3 of a pair without an x0 + 1 (odd width) would lie past the row's right border: it only feeds the discarded
   // Y(x0 + 1), so that row reads d1 again instead
   const int dx3 = o_off1[row_s] != kInvalidRow ? 2 * a.a_cs : 0;
   const unsigned a_lds = (unsigned)(row_s * 32 + (VY_SPLIT_SLOT(row_s, oct_s) << 4));
   const int KS = 3 * cch;
-  // W DMA: instruction q = j * 4 + wave of 24: image e = q / 12, row group g = (q % 12) / 3, plane p = q % 3
-  unsigned w_voff[6], w_lds[6];
+  // W DMA: instruction i = j * NW + wave of 24: image e = i / 12, row group g = (i % 12) / 3, plane p = i % 3
+  unsigned w_voff[WJ], w_lds[WJ];
+  bool w_img[WJ];  // wave-uniform
 #pragma unroll
-  for (int j = 0; j < 6; ++j) {
-    const int q = (j * NW + wave) % 12, g = q / 3, p = q - g * 3;
+  for (int j = 0; j < WJ; ++j) {
+    const int i = j * NW + wave, q = i % 12, g = q / 3, p = q - g * 3;
+    w_img[j] = i >= 12;
     w_voff[j] = (unsigned)(g * KS * 3072 + p * 1024 + lane * 16);
-    w_lds[j] = (unsigned)(W_BASE + (j >= 3 ? W_XI : 0) + p * W_PL + g * 1024);
+    w_lds[j] = (unsigned)(W_BASE + (w_img[j] ? W_XI : 0) + p * W_PL + g * 1024);
   }
   f32x16 acc[4][TNs];
 #pragma unroll
@@ -159,7 +170,8 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvArgs a, con
     // V_0 = d0 - d2   V_1 = d1 + d2   V_2 = d2 - d1   V_3 = d1 - d3     (offsets of the minuend / first and the second pixel)
     const int dxp = PH == 0 ? (e_s == 0 ? -a.a_cs : 0) : (e_s == 0 ? a.a_cs : 0);
     const int dxq = PH == 0 ? a.a_cs : (e_s == 0 ? 0 : dx3);
-    const bool add = PH == 0 && e_s == 1;
+    const float sg = PH == 0 && e_s == 1 ? 1.0f : -1.0f;
+    const f32x4 sgn = {sg, sg, sg, sg};
     const unsigned char* w_tile0 =
         reinterpret_cast<const unsigned char*>(a.w_split) + (2 * PH) * wimg_bytes + (long long)(n0 >> 5) * KS * 3072;
     const unsigned char* w_tile1 = w_tile0 + wimg_bytes;
@@ -176,23 +188,33 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvArgs a, con
     };
     f32x4 pp[2], pq[2];
     auto load_a = [&]() {
+      if (VY_WINO_ABL & 1) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) asm volatile("" : "+v"(pp[0][e]), "+v"(pp[1][e]), "+v"(pq[0][e]), "+v"(pq[1][e]));
+        return;
+      }
       const f32x4* x0 = reinterpret_cast<const f32x4*>(a_ptr + a_koff + dxp);
       const f32x4* x1 = reinterpret_cast<const f32x4*>(a_ptr + a_koff + dxq);
       pp[0] = x0[0], pp[1] = x0[1];
       pq[0] = x1[0], pq[1] = x1[1];
     };
     auto dma_w = [&](int stage) {
+      if (VY_WINO_ABL & 4) return;
 #pragma unroll
-      for (int j = 0; j < 6; ++j)
-        lds_dma16_s(w_voff[j], reinterpret_cast<const float*>((j >= 3 ? w_tile1 : w_tile0) + w_koff), lds0 + stage * W_ST + w_lds[j]);
+      for (int j = 0; j < WJ; ++j)
+        lds_dma16_s(w_voff[j], reinterpret_cast<const float*>((w_img[j] ? w_tile1 : w_tile0) + w_koff), lds0 + stage * W_ST + w_lds[j]);
     };
     auto store_a = [&](int stage) {
-      f32x4 u0, u1;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        u0[e] = add ? pp[0][e] + pq[0][e] : pp[0][e] - pq[0][e];
-        u1[e] = add ? pp[1][e] + pq[1][e] : pp[1][e] - pq[1][e];
+      if (VY_WINO_ABL & 2) {
+        unsigned char* d = smem + stage * A_ST + e_s * A_XI + a_lds;
+        *reinterpret_cast<f32x4*>(d) = pp[0];
+        *reinterpret_cast<f32x4*>(d + A_PL) = pp[1];
+        *reinterpret_cast<f32x4*>(d + 2 * A_PL) = pq[0];
+        return;
       }
+      // V = p +- q as fma(q, +-1, p): the product is exact, so this IS the rounded sum / difference — one (packed)
+      // instruction per channel pair instead of an add, a subtract and a select on the wave-uniform `add`
+      const f32x4 u0 = __builtin_elementwise_fma(pq[0], sgn, pp[0]), u1 = __builtin_elementwise_fma(pq[1], sgn, pp[1]);
       vy_u32x4 H, M, L;
       split8(u0, u1, H, M, L);
       unsigned char* d = smem + stage * A_ST + e_s * A_XI + a_lds;
@@ -206,9 +228,24 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvArgs a, con
         bf16x8 af[3], wf[3][TNs];
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
+          if (VY_WINO_ABL & 16) {
+            asm volatile("" : "=v"(af[p]));
+#pragma unroll
+            for (int j = 0; j < TNs; ++j) asm volatile("" : "=v"(wf[p][j]));
+            continue;
+          }
           af[p] = *reinterpret_cast<const bf16x8*>(sa + e * A_XI + fa + p * A_PL);
 #pragma unroll
           for (int j = 0; j < TNs; ++j) wf[p][j] = *reinterpret_cast<const bf16x8*>(sw + e * W_XI + fw + p * W_PL + j * 1024);
+        }
+        if (VY_WINO_ABL & 8) {
+#pragma unroll
+          for (int p = 0; p < 3; ++p) {
+            asm volatile("" ::"v"(af[p]));
+#pragma unroll
+            for (int j = 0; j < TNs; ++j) asm volatile("" ::"v"(wf[p][j]));
+          }
+          continue;
         }
         constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};  // (l,h) (h,l) (m,m) (m,h) (h,m) (h,h)
 #pragma unroll
@@ -243,6 +280,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvArgs a, con
       }
     };
     lds_barrier();  // the previous phase's last k-step may still be reading
+    if (VY_WINO_ABL & 1) pp[0] = pp[1] = pq[0] = pq[1] = f32x4{1.f, 2.f, 3.f, 4.f};
     advance_a();
     load_a();
     advance_w();
@@ -328,9 +366,16 @@ bool vy_conv_wino_supported(const ConvArgs& a) {
   return true;
 }
 
-static long long wino_tiles(const ConvArgs& a) {
+static long long wino_tiles(const ConvArgs& a, int bm) {
   const long long pairs = (long long)a.B * a.LH * ((a.LW + 1) / 2);
-  return ((pairs + 63) / 64) * (a.N / 128);
+  return ((pairs + bm - 1) / bm) * (a.N / 128);
+}
+
+// pairs per block of the launch (VY_WINO_BM=64 / 128: probes)
+static int wino_bm(const ConvArgs& a) {
+  const char* f = getenv("VY_WINO_BM");
+  if (f && (atoi(f) == 64 || atoi(f) == 128)) return atoi(f);
+  return 64;
 }
 
 // Per launch, where the cost models say it wins (conv_cost_model.h: vy_predict_wino against the split kernel's and the
@@ -342,13 +387,15 @@ bool vy_conv_wino_pays(const ConvArgs& a) {
   const int mode = sw ? atoi(sw) : 1;
   if (mode == 0) return false;
   if (mode == 2) return true;
+  const int cus = vy_cu_count();
+  if (!vy_model_fitted(cus)) return false;  // fitted on 256 CUs (conv_cost_model.h)
   const long long pairs = (long long)a.B * a.LH * ((a.LW + 1) / 2);
-  const double t_wino = vy_predict_wino(pairs, a.N, a.Kc);
+  const double t_wino = vy_predict_wino(pairs, a.N, a.Kc, cus);
   double t_other = vy_conv_predict_us(a);
   if (vy_conv_split_supported(a)) {
     const long long max_ks = a.splitk_slabs ? std::max<long long>(1, (long long)(a.splitk_bytes / ((unsigned long long)a.M * a.N * 4ull))) : 1;
     int bm, bn, ks;
-    t_other = std::min(t_other, vy_predict_split(a.M, a.N, 9.0 * a.Kc, (int)std::min<long long>(max_ks, 64), &bm, &bn, &ks));
+    t_other = std::min(t_other, vy_predict_split(a.M, a.N, 9.0 * a.Kc, (int)std::min<long long>(max_ks, 64), &bm, &bn, &ks, cus));
   }
   return t_wino < 0.97 * t_other;
 }
@@ -358,7 +405,9 @@ hipError_t vy_launch_conv_wino(const ConvArgs& a, hipStream_t s) {
   const int Wp2 = (a.LW + 1) / 2, Mp = a.B * a.LH * Wp2, tiles_n = a.N / 128;
   ConvArgs k = a;
   k.w_split = a.w_wino;  // (the kernel reads its images through the same field)
-  hipLaunchKernelGGL(conv_wino_kernel, dim3((unsigned)wino_tiles(a)), dim3(256), 0, s, k, tiles_n, Wp2, Mp,
-                     (long long)vy_split_weight_bytes(a.w_cout, 3, a.Kc));
+  const int bm = wino_bm(a);
+  const long long wb = (long long)vy_split_weight_bytes(a.w_cout, 3, a.Kc);
+  if (bm == 128) hipLaunchKernelGGL(conv_wino_kernel<128>, dim3((unsigned)wino_tiles(a, 128)), dim3(512), 0, s, k, tiles_n, Wp2, Mp, wb);
+  else hipLaunchKernelGGL(conv_wino_kernel<64>, dim3((unsigned)wino_tiles(a, 64)), dim3(256), 0, s, k, tiles_n, Wp2, Mp, wb);
   return hipGetLastError();
 }

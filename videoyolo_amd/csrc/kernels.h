@@ -71,6 +71,7 @@ hipError_t vy_launch_conv_s16(const ConvArgs& a, int bm, int bn, hipStream_t s);
 int vy_conv_tiles_m(const ConvArgs& a);
 void vy_conv_cfg(const ConvArgs& a, int* bm, int* bn);  // block tile the launch will use
 double vy_conv_predict_us(const ConvArgs& a);             // the cost model's time for the launch (conv_cost_model.h)
+int vy_cu_count();                                        // CUs of the current device (what the cost models count rounds in)
 bool vy_conv_streamk(const ConvArgs& a);                  // ... and whether it will be a stream-K launch (label "<BM>x<BN>sk")
 
 // stream-K is enabled per net only after this has seen the MI355X's SPX placement (8 XCDs, blocks L and L + 8 on one

@@ -69,7 +69,7 @@ size_t vy_net_param_bytes(const vy_net* net) { return net ? (size_t)net->param_e
 int vy_net_bind_params(vy_net* net, void* dev_params) {
   if (!net || !dev_params) return fail(VY_ERR_INVALID, "null argument");
   net->dev_params = static_cast<float*>(dev_params);
-  net->split_dirty = net->dsplit_dirty = true;
+  net->split_dirty = net->dsplit_dirty = net->wino_dirty = true;
   return 0;
 }
 
@@ -91,7 +91,7 @@ int vy_net_param_set(vy_net* net, int32_t i, const float* host_src, void* stream
   const vy_param_info& pi = net->params[i].info;
   hipStream_t s = static_cast<hipStream_t>(stream);
   float* dst = net->dev_params + pi.offset;
-  net->split_dirty = net->dsplit_dirty = true;
+  net->split_dirty = net->dsplit_dirty = net->wino_dirty = true;
   if (pi.ndim == 4) {
     std::vector<float> tmp((size_t)pi.size);
     pack_oihw(host_src, tmp.data(), pi.shape[0], pi.shape[1], pi.shape[2]);
@@ -184,7 +184,7 @@ int vy_net_streamk_state(const vy_net* net, int32_t* enabled, size_t* flags_offs
 
 int vy_net_invalidate_split_weights(vy_net* net) {
   if (!net) return fail(VY_ERR_INVALID, "net is null");
-  net->split_dirty = net->dsplit_dirty = true;
+  net->split_dirty = net->dsplit_dirty = net->wino_dirty = true;
   return 0;
 }
 

@@ -87,6 +87,10 @@ struct vy_net {
   int conv_mode = 0;
   bool split_dirty = true;    // the forward weight images are stale
   bool dsplit_dirty = true;   // the data-gradient weight images (training plans; train.hip) are stale
+  // the Winograd image sets (conv_wino.hip) are stale.  Their own flag: a training plan holds them too (model.py reuses it
+  // for inference at the same size) but train.hip's refresh_split_images rebuilds only the forward and data-gradient sets —
+  // only forward() below, which does rebuild them, may clear it
+  bool wino_dirty = true;
   size_t wsplit_off = 0;
   struct VyTrain* train = nullptr;  // training planner state, owned by train.hip
 
@@ -364,7 +368,7 @@ struct vy_net {
       det_scratch_off = det_off;
       sk_off = sk_o;
       wsplit_off = wsp_off;
-      split_dirty = dsplit_dirty = true;
+      split_dirty = dsplit_dirty = wino_dirty = true;
       planes_off = pl_off;
       B = b;
       H = h;
@@ -512,18 +516,18 @@ struct vy_net {
     hook("bn_fold", 0.0, 0.0, true);
     HIP_TRY(vy_launch_bn_fold(dev_params, fd, (int)folds.size(), 1024, 1e-5f, s));
     hook("bn_fold", 0.0, 0.0, false);
-    if (conv_mode != VY_CONV_EXACT_FP32 && split_dirty) {  // once per parameter change, not per forward
+    if (conv_mode != VY_CONV_EXACT_FP32 && (split_dirty || wino_dirty)) {  // once per parameter change, not per forward
       hook("split_weights", 0.0, 0.0, true);
       for (const ConvT& c : convs)
-        if (c.split_off >= 0)
+        if (split_dirty && c.split_off >= 0)
           HIP_TRY(vy_launch_split_weights(dev_params + params[c.p_weight].info.offset, dev_ws + wsplit_off + c.split_off,
                                           c.cout, c.k * c.k, c.cin, s));
       for (const ConvT& c : convs)
-        if (c.wino_off >= 0)
+        if (wino_dirty && c.wino_off >= 0)
           HIP_TRY(vy_launch_wino_weights(dev_params + params[c.p_weight].info.offset, dev_ws + wsplit_off + c.wino_off, c.cout,
                                          c.cin, s));
       hook("split_weights", 0.0, 0.0, false);
-      split_dirty = false;
+      split_dirty = wino_dirty = false;
     }
     for (const ConvT& c : convs) {
       if (c.is_stem) {

@@ -26,19 +26,24 @@ __device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
   return r;
 }
 
-// 8 consecutive channels -> the three bf16 planes (4 dwords each)
+typedef float vy_f32x2 __attribute__((ext_vector_type(2)));
+
+// 8 consecutive channels -> the three bf16 planes (4 dwords each).  The two differences of a channel pair are written
+// as 2-vectors: hipcc issues them as one v_pk_add_f32 (negated operand) — 9 instead of 11 vector instructions per pair,
+// same IEEE results
 __device__ __forceinline__ void split8(const f32x4 v0, const f32x4 v1, vy_u32x4& H, vy_u32x4& M, vy_u32x4& L) {
-  const float x[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+  const vy_f32x2 x[4] = {{v0[0], v0[1]}, {v0[2], v0[3]}, {v1[0], v1[1]}, {v1[2], v1[3]}};
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    const float x0 = x[2 * j], x1 = x[2 * j + 1];
-    const unsigned h = cvt_pk_bf16(x0, x1);
-    const float r0 = x0 - __builtin_bit_cast(float, h << 16), r1 = x1 - __builtin_bit_cast(float, h & 0xffff0000u);
-    const unsigned m = cvt_pk_bf16(r0, r1);
-    const float l0 = r0 - __builtin_bit_cast(float, m << 16), l1 = r1 - __builtin_bit_cast(float, m & 0xffff0000u);
+    const unsigned h = cvt_pk_bf16(x[j][0], x[j][1]);
+    const vy_f32x2 hf = {__builtin_bit_cast(float, h << 16), __builtin_bit_cast(float, h & 0xffff0000u)};
+    const vy_f32x2 r = x[j] - hf;
+    const unsigned m = cvt_pk_bf16(r[0], r[1]);
+    const vy_f32x2 mf = {__builtin_bit_cast(float, m << 16), __builtin_bit_cast(float, m & 0xffff0000u)};
+    const vy_f32x2 l = r - mf;
     H[j] = h;
     M[j] = m;
-    L[j] = cvt_pk_bf16(l0, l1);
+    L[j] = cvt_pk_bf16(l[0], l[1]);
   }
 }
 #endif

@@ -201,9 +201,10 @@ size_t train_plan(vy_net* net, int b, int h, int w, bool commit) {
       // cheapest (splits, k_per_split) under that model is taken; a split is >= 256 pixels.
       long long best_k = ((M + 31) / 32) * 32, best_sp = 1;
       double best_cost = 1e300;
+      const long long held = 2ll * vy_cu_count();  // blocks the device holds at a time (512 on the MI355X)
       for (long long k = 256; k <= ((M + 31) / 32) * 32; k += 32) {
         const long long sp_k = (M + k - 1) / k;
-        const long long rounds = (tiles * sp_k + 511) / 512;
+        const long long rounds = (tiles * sp_k + held - 1) / held;
         const double cost = (double)rounds * ((double)k / 32.0 + 3.0);
         if (cost < best_cost) {
           best_cost = cost;
@@ -1036,7 +1037,7 @@ int vy_net_sgd_step(vy_net* net, float lr, float momentum, float wd, float resca
   }
   HIP_TRY(vy_launch_sgd(net->dev_params, t->grads, t->mom, segs, chunks, (int)(t->chunk_seg.size() / 2), lr, momentum,
                         wd, rescale_grad, s));
-  net->split_dirty = net->dsplit_dirty = true;  // conv mode VY_CONV_SPLIT_BF16X3: the weight images are stale now
+  net->split_dirty = net->dsplit_dirty = net->wino_dirty = true;  // conv mode VY_CONV_SPLIT_BF16X3: the weight images are stale now
   return 0;
 }
 

@@ -79,6 +79,7 @@ def group_timeout():
 
 def init_process_group(backend=None):
     """Initialise from the torchrun environment (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_*)."""
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # see videoyolo_amd/__init__.py; effective while no GPU call has been made
     import torch
     dist = _dist()
     if dist.is_initialized():
