@@ -87,6 +87,27 @@ int vy_net_set_nms(vy_net* net, float nms_thresh, int32_t nms_topk, int32_t post
 int32_t vy_net_num_params(const vy_net* net);
 int vy_net_param_info(const vy_net* net, int32_t i, vy_param_info* out);
 
+/* The graph the planner executes, one row per convolution in EXECUTION order (host-only; no device needed): what
+ * `net.summary(x)` (train_yolov3.py:758) prints per layer, and what tests/test_graph_structure.py compares with the
+ * structure the reference's own constructors build (wrappers.py:54-58,80-103; three_darknet.py:162-195;
+ * yolo3.py:218-263,1013-1054; layers.py:63-70) — tests/golden/graph_structure.json. */
+typedef struct vy_conv_info {
+  char name[96];        /* structural prefix of the cell ("stages.0.2.body.1"; the Conv2D itself is "<name>.0") or of the
+                           prediction conv ("yolo_outputs.0.prediction") */
+  int32_t cin, cout, kernel, stride, pad;
+  int32_t has_bn;       /* 1: Conv2D(use_bias=False) -> norm_layer -> LeakyReLU(0.1) (layers.py:63-70); 0: bias, no activation */
+  int32_t sync_bn;      /* 1: the cell is built with the norm_layer passed to yolo3_darknet53 (SyncBatchNorm exchanges its
+                           statistics there); 0: hard-wired / defaulted BatchNorm (darknet.py:89-91, wrappers.py:101-103) */
+  int32_t residual;     /* 1: the block's input is added to this cell's output (darknet.py:40) */
+  int32_t upsample;     /* 2: the output is stored x2-replicated and cropped into the concat plane (layers.py:11-20,
+                           yolo3.py:1167-1177); 1 otherwise */
+  int32_t concat_offset;/* first channel of this conv's output inside its output plane (concat fusion: the upsampled
+                           transition comes FIRST, the backbone route after it) */
+  int32_t out_channels_total; /* channels of that output plane */
+} vy_conv_info;
+int32_t vy_net_num_convs(const vy_net* net);
+int vy_net_conv_info(const vy_net* net, int32_t i, vy_conv_info* out);
+
 /* Bytes of the device parameter buffer (all tensors + folded-BN scratch). */
 size_t vy_net_param_bytes(const vy_net* net);
 /* Bind the caller-owned device parameter buffer (net.collect_params().reset_ctx(ctx),

@@ -1,0 +1,461 @@
+#!/usr/bin/env python3
+"""Records the STRUCTURE the reference's own constructors build for ``yolo3_darknet53`` and writes
+tests/golden/graph_structure.json.  Build container only (reads /root/reference; nothing of it is copied).
+
+What this is.  ``mxnet`` / ``gluoncv`` do not exist here, so the reference cannot compute anything.  But its model
+DEFINITION is plain Python: ``models/definitions/yolo/wrappers.py:9-110`` calls ``get_darknet`` (three_darknet.py),
+slices ``features[:15] / [15:24] / [24:]``, and builds ``YOLOV3T`` (yolo3.py:915-1054), which builds its detection
+blocks, transitions and output layers through ``_conv2d`` (layers.py:63-70).  This script imports those files under a
+RECORDING stand-in for the ``mxnet`` / ``gluoncv`` module trees: ``Block`` / ``HybridSequential`` keep their children by
+name exactly as Gluon does (attribute name, or the running index inside a sequential — the structural names that
+``save_parameters`` writes), ``Conv2D`` / ``BatchNorm`` / ``SyncBatchNorm`` / ``LeakyReLU`` record their constructor
+arguments, and a forward pass with a shape-less tensor stand-in that only carries a CHANNEL COUNT runs the reference's
+own ``hybrid_forward`` methods, so that every Conv2D learns its input channels (Gluon infers them the same way, at the
+first forward) and the order in which the reference EXECUTES its convs, concats and the ``box_nms`` call is written
+down together with the non-tensor arguments of every operator call.
+
+What this is NOT.  No arithmetic of mxnet is reproduced or pretended: the stand-in tensors hold no values, no operator
+computes anything, and nothing here says what ``Convolution``, ``BatchNorm``, ``box_nms`` or ``YOLOV3Loss`` return.
+The fixture therefore pins rows a2-a6 / a13 of SURVEY section 8 (graph, channel plan, which cells take the passed
+norm_layer, anchors / strides per head, concat order, operator call parameters, parameter counts) to the reference's
+executed constructors instead of a reading of them — it does NOT lift the oracle from "parity unpinned" (DESIGN 2).
+
+    python tests/golden/make_graph_structure.py            # writes tests/golden/graph_structure.json
+"""
+import collections
+import contextlib
+import importlib.abc
+import importlib.machinery
+import json
+import os
+import sys
+import types
+
+REF = "/root/reference"
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "graph_structure.json")
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# shape-less tensor: carries a channel count (or None) and records nothing by itself
+# ------------------------------------------------------------------------------------------------------------------
+class T:
+    def __init__(self, c=None, tag=None):
+        self.c = c
+        self.tag = tag  # provenance label for the concat record
+
+    def _same(self, *a, **k):
+        return T(self.c, self.tag)
+
+    def __getattr__(self, name):
+        if name.startswith("__"):
+            raise AttributeError(name)
+
+        def method(*a, **k):
+            TRACE.op("x." + name, a, k)
+            return T(self.c, self.tag)
+        return method
+
+    def repeat(self, *a, **k):  # _upsample (layers.py:11-20): repeat on W, then H
+        TRACE.op("x.repeat", a, k)
+        return T(self.c, "upsample(%s)" % self.tag if not str(self.tag).startswith("upsample(") else self.tag)
+
+    __add__ = __radd__ = __sub__ = __rsub__ = __mul__ = __rmul__ = __truediv__ = __neg__ = _same
+
+    def __iter__(self):
+        raise TypeError("tensor stand-in is not iterable")
+
+
+def _plain(v):
+    """non-tensor arguments of an operator call, JSON-able"""
+    if isinstance(v, T):
+        return "<T>"
+    if isinstance(v, (list, tuple)):
+        return [_plain(u) for u in v]
+    if isinstance(v, (int, float, str, bool)) or v is None:
+        return v
+    return repr(v)
+
+
+class Trace:
+    def __init__(self):
+        self.reset()
+
+    def reset(self):
+        self.ops, self.convs, self.norms, self.acts, self.concats, self.stack = [], [], [], [], [], []
+
+    def op(self, name, a, k):
+        self.ops.append({"op": name, "in": self.stack[-1] if self.stack else "", "args": [_plain(v) for v in a if not isinstance(v, T)],
+                         "kwargs": {kk: _plain(v) for kk, v in sorted(k.items())}})
+
+
+TRACE = Trace()
+
+
+class FNamespace:
+    """stand-in for the ``F`` argument of hybrid_forward (mx.nd / mx.sym): every operator returns a tensor stand-in with
+    the channel count of its first tensor argument; concat along axis 1 adds the counts"""
+
+    def __init__(self, prefix="F."):
+        self._p = prefix
+
+    def __getattr__(self, name):
+        if name.startswith("__"):
+            raise AttributeError(name)
+        if name == "contrib":
+            return FNamespace(self._p + "contrib.")
+
+        def fn(*a, **k):
+            TRACE.op(self._p + name, a, k)
+            ts = [v for v in a if isinstance(v, T)]
+            if name == "concat":
+                dim = k.get("dim", 1)
+                rec = {"in": TRACE.stack[-1] if TRACE.stack else "", "dim": dim, "channels": [t.c for t in ts], "inputs": [t.tag for t in ts]}
+                TRACE.concats.append(rec)
+                if dim == 1 and all(t.c is not None for t in ts):
+                    return T(sum(t.c for t in ts), "concat")
+                return T(None, "concat")
+            return T(ts[0].c, ts[0].tag) if ts else T(None)
+        return fn
+
+
+F = FNamespace()
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Gluon's container semantics: children by attribute name / running index; parameters by name
+# ------------------------------------------------------------------------------------------------------------------
+class Param:
+    def __init__(self, name, value=None, **kw):
+        self.name, self.value, self.grad_req, self.kw = name, value, "write", kw
+        self.wd_mult = self.lr_mult = 1.0
+
+
+class ParamDict(collections.OrderedDict):
+    def get(self, name, **kw):  # noqa: A003
+        if name not in self:
+            self[name] = Param(name, **kw)
+        return self[name]
+
+    def get_constant(self, name, value=None):
+        import numpy as np
+        if name not in self:
+            self[name] = Param(name, value=np.asarray(value))
+            self[name].grad_req = "null"
+        return self[name]
+
+    def reset_ctx(self, ctx):
+        pass
+
+
+class Block:
+    def __init__(self, prefix=None, params=None, **kw):
+        object.__setattr__(self, "_children", collections.OrderedDict())
+        object.__setattr__(self, "_reg_params", collections.OrderedDict())
+        object.__setattr__(self, "params", ParamDict())
+        object.__setattr__(self, "_prefix", prefix or "")
+        object.__setattr__(self, "_extra_kw", kw)
+
+    @property
+    def prefix(self):
+        return self._prefix
+
+    def name_scope(self):
+        return contextlib.nullcontext()
+
+    def __setattr__(self, name, value):
+        if isinstance(value, Block):
+            self._children[name] = value
+        elif isinstance(value, Param):
+            self._reg_params[name] = value
+        object.__setattr__(self, name, value)
+
+    def register_child(self, block, name=None):
+        self._children[str(len(self._children)) if name is None else name] = block
+
+    def collect_params(self, select=None):
+        out = ParamDict()
+        for path, b in walk(self):
+            for n, p in b.params.items():
+                out[(path + "." if path else "") + n] = p
+        return out
+
+    def hybridize(self, *a, **k):
+        pass
+
+    def initialize(self, *a, **k):
+        pass
+
+    def _clear_cached_op(self):
+        pass
+
+    def __call__(self, *args):
+        TRACE.stack.append(getattr(self, "_path", type(self).__name__))
+        try:
+            return self.forward(*args)
+        finally:
+            TRACE.stack.pop()
+
+    def forward(self, *args):
+        raise NotImplementedError(type(self).__name__)
+
+
+class HybridBlock(Block):
+    def forward(self, x, *args):
+        params = {n: T(None, "const:" + n) for n in self._reg_params}
+        return self.hybrid_forward(F, x, *args, **params)
+
+
+class HybridSequential(HybridBlock):
+    def add(self, *blocks):
+        for b in blocks:
+            self.register_child(b)
+
+    def hybrid_forward(self, F, x):
+        for b in self._children.values():
+            x = b(x)
+        return x
+
+    def __getitem__(self, key):
+        layers = list(self._children.values())[key]
+        if isinstance(layers, list):
+            net = type(self)(prefix=self._prefix)  # gluon: a slice is a NEW sequential, children re-indexed from 0
+            net.add(*layers)
+            return net
+        return layers
+
+    def __len__(self):
+        return len(self._children)
+
+    def __iter__(self):
+        return iter(self._children.values())
+
+
+Sequential = HybridSequential
+
+
+def _pair(v):
+    return [int(v), int(v)] if isinstance(v, int) else [int(u) for u in v]
+
+
+class Conv2D(HybridBlock):
+    def __init__(self, channels, kernel_size, strides=(1, 1), padding=(0, 0), dilation=(1, 1), groups=1, layout="NCHW",
+                 activation=None, use_bias=True, weight_initializer=None, bias_initializer="zeros", in_channels=0, **kw):
+        super().__init__(**kw)
+        self.spec = {"cout": int(channels), "kernel": _pair(kernel_size), "stride": _pair(strides), "pad": _pair(padding),
+                     "dilation": _pair(dilation), "groups": int(groups), "layout": layout, "activation": activation,
+                     "use_bias": bool(use_bias), "in_channels_declared": int(in_channels)}
+        self.weight = self.params.get("weight")
+        if use_bias:
+            self.bias = self.params.get("bias")
+
+    def forward(self, x):
+        rec = dict(self.spec, cin=x.c, name=self._path, exec_index=len(TRACE.convs))
+        TRACE.convs.append(rec)
+        return T(self.spec["cout"], self._path)
+
+
+class _Norm(HybridBlock):
+    def __init__(self, *a, **kw):
+        super().__init__()
+        self.ctor_args, self.ctor_kwargs = [_plain(v) for v in a], {k: _plain(v) for k, v in sorted(kw.items())}
+        for n in ("gamma", "beta", "running_mean", "running_var"):
+            setattr(self, n, self.params.get(n))
+
+    def forward(self, x):
+        TRACE.norms.append({"name": self._path, "class": type(self).__name__, "channels": x.c, "kwargs": self.ctor_kwargs,
+                            "args": self.ctor_args})
+        return T(x.c, x.tag)
+
+
+class BatchNorm(_Norm):
+    pass
+
+
+class SyncBatchNorm(_Norm):
+    pass
+
+
+class LeakyReLU(HybridBlock):
+    def __init__(self, alpha, **kw):
+        super().__init__(**kw)
+        self.alpha = float(alpha)
+
+    def forward(self, x):
+        TRACE.acts.append({"name": self._path, "class": "LeakyReLU", "alpha": self.alpha})
+        return T(x.c, x.tag)
+
+
+def walk(block, path=""):
+    yield path, block
+    for name, child in block._children.items():
+        yield from walk(child, (path + "." if path else "") + name)
+
+
+def name_paths(root):
+    for path, b in walk(root):
+        object.__setattr__(b, "_path", path)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# permissive module trees for `mxnet` and `gluoncv`: anything not given above is a subclassable, callable placeholder
+# ------------------------------------------------------------------------------------------------------------------
+class Anything:
+    def __init__(self, *a, **k):
+        pass
+
+    def __call__(self, *a, **k):
+        return Anything()
+
+    def __getattr__(self, name):
+        if name.startswith("__"):
+            raise AttributeError(name)
+        return Anything()
+
+
+class _Autograd(types.ModuleType):
+    training = False
+    recording = False
+
+    def is_training(self):
+        return self.training
+
+    def is_recording(self):
+        return self.recording
+
+    def pause(self):
+        return contextlib.nullcontext()
+
+
+KNOWN = {
+    "mxnet.gluon": {"Block": Block, "HybridBlock": HybridBlock},
+    "mxnet.gluon.nn": {"Block": Block, "HybridBlock": HybridBlock, "HybridSequential": HybridSequential, "Sequential": Sequential,
+                       "Conv2D": Conv2D, "BatchNorm": BatchNorm, "LeakyReLU": LeakyReLU},
+    "mxnet.gluon.contrib.nn": {"SyncBatchNorm": SyncBatchNorm},
+}
+
+
+class _Permissive(types.ModuleType):
+    def __getattr__(self, name):
+        if name.startswith("__"):
+            raise AttributeError(name)
+        full = self.__name__ + "." + name
+        if full in sys.modules:
+            return sys.modules[full]
+        cls = type(name, (Anything,), {"__module__": self.__name__})
+        setattr(self, name, cls)
+        return cls
+
+
+class _Finder(importlib.abc.MetaPathFinder, importlib.abc.Loader):
+    ROOTS = ("mxnet", "gluoncv")
+
+    def find_spec(self, fullname, path=None, target=None):
+        if fullname.split(".")[0] in self.ROOTS:
+            return importlib.machinery.ModuleSpec(fullname, self, is_package=True)
+        return None
+
+    def create_module(self, spec):
+        if spec.name == "mxnet.autograd":
+            m = _Autograd(spec.name)
+        else:
+            m = _Permissive(spec.name)
+        m.__path__ = []
+        for k, v in KNOWN.get(spec.name, {}).items():
+            setattr(m, k, v)
+        return m
+
+    def exec_module(self, module):
+        parent, _, leaf = module.__name__.rpartition(".")
+        if parent and parent in sys.modules:
+            setattr(sys.modules[parent], leaf, module)
+
+
+def install():
+    sys.meta_path.insert(0, _Finder())
+    import mxnet  # noqa: F401
+    import mxnet.gluon  # noqa: F401
+    import mxnet.gluon.nn  # noqa: F401
+    import mxnet.gluon.contrib.nn  # noqa: F401
+    import mxnet.autograd  # noqa: F401
+    sys.path.insert(0, REF)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+def record(num_class, sync):
+    """build yolo3_darknet53 as train_yolov3.py:347-360 / detect_yolo3.py:873-880 do and run one inference-mode forward"""
+    import numpy as np
+    from models.definitions.yolo.wrappers import yolo3_darknet53
+    import mxnet
+    classes = ["c%d" % i for i in range(num_class)]
+    kw = dict(pretrained_base=False, k=1)
+    if sync:
+        kw.update(norm_layer=mxnet.gluon.contrib.nn.SyncBatchNorm, norm_kwargs={"num_devices": 8})
+    net = yolo3_darknet53(classes, **kw)
+    name_paths(net)
+    TRACE.reset()
+    mxnet.autograd.training = False
+    out = net(T(3, "input"))
+    assert isinstance(out, tuple) and len(out) == 3, "inference mode returns (ids, scores, bboxes)"
+    convs, norms, acts = TRACE.convs, {n["name"]: n for n in TRACE.norms}, {a["name"]: a for a in TRACE.acts}
+    rows = []
+    for c in convs:
+        cell = c["name"].rsplit(".", 1)[0] if c["name"].endswith(".0") else None  # _conv2d: [Conv2D, norm, LeakyReLU]
+        norm = norms.get(cell + ".1") if cell else None
+        act = acts.get(cell + ".2") if cell else None
+        rows.append({"exec_index": c["exec_index"], "name": c["name"], "cin": c["cin"], "cout": c["cout"], "kernel": c["kernel"],
+                     "stride": c["stride"], "pad": c["pad"], "use_bias": c["use_bias"], "groups": c["groups"],
+                     "norm": None if norm is None else {"name": norm["name"], "class": norm["class"], "kwargs": norm["kwargs"]},
+                     "act": None if act is None else {"class": act["class"], "alpha": act["alpha"]}})
+    heads = []
+    for i, o in enumerate(net.yolo_outputs):
+        heads.append({"index": i, "anchors": np.asarray(o.anchors.value).reshape(-1).tolist(), "stride": int(o._stride),
+                      "num_pred": int(o._num_pred), "num_anchors": int(o._num_anchors),
+                      "offsets_shape": list(np.asarray(o.offsets.value).shape),
+                      "offsets_first_xy": np.asarray(o.offsets.value)[0, 0, 1, 2].tolist()})  # (y = 1, x = 2) -> [2, 1]
+    weights = sum(r["cout"] * r["cin"] * r["kernel"][0] * r["kernel"][1] // r["groups"] for r in rows)
+    biases = sum(r["cout"] for r in rows if r["use_bias"])
+    bn_ch = sum(n["channels"] for n in TRACE.norms)
+    params = collections.OrderedDict((k, v) for k, v in net.collect_params().items())
+    return {
+        "num_class": num_class,
+        "norm_layer": "SyncBatchNorm(num_devices=8)" if sync else "BatchNorm (default)",
+        "convs": rows,
+        "stage_lengths": [len(s) for s in net.stages],
+        "heads": heads,
+        "concats_axis1": [c for c in TRACE.concats if c["dim"] == 1 and c["in"] == ""],
+        "cells_with_the_passed_norm_layer": sorted(n["name"] for n in TRACE.norms if n["class"] == "SyncBatchNorm"),
+        "norm_classes": collections.Counter(n["class"] for n in TRACE.norms),
+        "trainable_parameters": weights + biases + 2 * bn_ch,
+        "running_statistics": 2 * bn_ch,
+        "parameter_names": [k for k in params if not k.rsplit(".", 1)[-1].startswith(("anchor_", "offset_"))],
+        "nms_defaults": {"nms_thresh": net.nms_thresh, "nms_topk": net.nms_topk, "post_nms": net.post_nms},
+        "ops_top_level": [o for o in TRACE.ops if o["in"] == ""],
+        "ops_output_layer_0": [o for o in TRACE.ops if o["in"] == "yolo_outputs.0"],
+    }
+
+
+def main():
+    install()
+    doc = {
+        "what": "STRUCTURE ONLY: recorded from the reference's own constructors and hybrid_forward methods under a "
+                "recording stand-in for mxnet/gluoncv (tests/golden/make_graph_structure.py). No operator arithmetic is "
+                "reproduced; this does not pin the oracle (DESIGN.md section 2).",
+        "reference_files": ["models/definitions/yolo/wrappers.py", "models/definitions/darknet/three_darknet.py",
+                            "models/definitions/darknet/darknet.py", "models/definitions/layers.py",
+                            "models/definitions/yolo/yolo3.py"],
+        "voc20": record(20, sync=False),
+        "vid30": record(30, sync=False),
+        "voc20_syncbn8": record(20, sync=True),
+    }
+    with open(OUT, "w") as f:
+        json.dump(doc, f, indent=1, sort_keys=False)
+        f.write("\n")
+    for k in ("voc20", "vid30", "voc20_syncbn8"):
+        d = doc[k]
+        print(k, len(d["convs"]), "convs,", d["trainable_parameters"], "trainable,", dict(d["norm_classes"]),
+              "stages", d["stage_lengths"])
+    print("wrote", OUT, os.path.getsize(OUT), "bytes")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,214 @@
+"""-m "not gpu": the graph the planner executes (vy_net_num_convs / vy_net_conv_info / vy_net_param_info, host-only)
+against tests/golden/graph_structure.json — the structure the REFERENCE's own constructors and hybrid_forward methods
+build, recorded by tests/golden/make_graph_structure.py under a recording stand-in for mxnet / gluoncv (build container
+only; the fixture is data: names, channel counts, constructor arguments, operator-call parameters).
+
+STRUCTURE ONLY.  The fixture holds no number any mxnet operator computed, so this settles mechanically what a reading of
+the reference could get wrong (SURVEY section 2 said 26 cells take SyncBatchNorm: it is 6) and ties rows a2-a6 / a13 of
+SURVEY section 8 to executed reference code — it does NOT pin the oracle's arithmetic (DESIGN.md section 2 stays
+"parity unpinned")."""
+import ctypes
+import inspect
+import json
+import os
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def golden():
+    with open(os.path.join(HERE, "golden", "graph_structure.json")) as f:
+        return json.load(f)
+
+
+def _net(ncls):
+    from videoyolo_amd import _lib
+    L = _lib.load()
+    h = ctypes.c_void_p()
+    _lib.check(L.vy_net_create(ncls, ctypes.byref(h)))
+    return L, h
+
+
+def _convs(ncls):
+    from videoyolo_amd import _lib
+    L, h = _net(ncls)
+    rows = []
+    ci = _lib.ConvInfo()
+    for i in range(L.vy_net_num_convs(h)):
+        _lib.check(L.vy_net_conv_info(h, i, ctypes.byref(ci)))
+        rows.append({f: (getattr(ci, f).decode() if f == "name" else int(getattr(ci, f))) for f, _ in _lib.ConvInfo._fields_})
+    L.vy_net_destroy(h)
+    return rows
+
+
+def _params(ncls):
+    from videoyolo_amd import _lib
+    L, h = _net(ncls)
+    rows = []
+    pi = _lib.ParamInfo()
+    for i in range(L.vy_net_num_params(h)):
+        _lib.check(L.vy_net_param_info(h, i, ctypes.byref(pi)))
+        rows.append((pi.name.decode(), int(pi.size), int(pi.trainable), [int(pi.shape[j]) for j in range(pi.ndim)], int(pi.backbone)))
+    L.vy_net_destroy(h)
+    return rows
+
+
+@pytest.mark.parametrize("key,ncls", [("voc20", 20), ("vid30", 30)])
+def test_conv_list_in_the_references_execution_order(golden, key, ncls):
+    """75 convs; every row — cell name, cin (which Gluon infers at the first forward: recorded by running the reference's
+    hybrid_forward methods), cout, kernel, stride, padding, bias or BatchNorm + LeakyReLU(0.1) — and the ORDER in which
+    YOLOV3T.hybrid_forward (yolo3.py:1105-1177) reaches them."""
+    ref, got = golden[key]["convs"], _convs(ncls)
+    assert len(ref) == len(got) == 75
+    for r, g in zip(ref, got):
+        cell = r["name"][:-2] if r["norm"] is not None else r["name"]  # _conv2d: HybridSequential [Conv2D, norm, LeakyReLU]
+        assert r["name"] == (cell + ".0" if r["norm"] is not None else cell)
+        assert g["name"] == cell, (r["exec_index"], g["name"], cell)
+        assert (g["cin"], g["cout"]) == (r["cin"], r["cout"]), cell
+        assert r["kernel"] == [g["kernel"]] * 2 and r["stride"] == [g["stride"]] * 2 and r["pad"] == [g["pad"]] * 2, cell
+        assert r["groups"] == 1
+        assert bool(g["has_bn"]) == (r["norm"] is not None) == (not r["use_bias"]), cell
+        if r["norm"] is not None:
+            assert r["norm"]["name"] == cell + ".1"
+            assert r["norm"]["kwargs"] == {"epsilon": 1e-05, "momentum": 0.9}, cell      # layers.py:68
+            assert r["act"] == {"class": "LeakyReLU", "alpha": 0.1}, cell                 # layers.py:69
+        else:
+            assert r["act"] is None and cell.endswith(".prediction") and g["cout"] == 3 * (5 + ncls)   # yolo3.py:60-62
+    assert sum(1 for g in got if g["has_bn"]) == 72
+
+
+def test_constants_the_kernels_compile_in(golden):
+    """eps / momentum / leaky slope of the recorded cells are the ones the library and the oracle use."""
+    from oracle import yolo3_oracle as O
+    import videoyolo_amd.model as M
+    assert inspect.signature(O.bn_fold).parameters["eps"].default == 1e-5
+    assert inspect.signature(O.bn_train).parameters["eps"].default == 1e-5
+    src = open(os.path.join(os.path.dirname(HERE), "include", "vy_math.h")).read()
+    assert "0.1f" in src  # vy_leaky
+    assert M.YOLOV3._ANCHORS == tuple(tuple(int(a) for a in h["anchors"]) for h in golden["voc20"]["heads"])
+
+
+@pytest.mark.parametrize("key,ncls", [("voc20", 20), ("vid30", 30)])
+def test_stage_split_residuals_and_concat_fusion(golden, key, ncls):
+    g = golden[key]
+    got = _convs(ncls)
+    by = {r["name"]: r for r in got}
+    # wrappers.py:58: features[:15] / [15:24] / [24:] — a slice of a HybridSequential is a new one, indexed from 0
+    assert g["stage_lengths"] == [15, 9, 5]
+    for s, n in enumerate(g["stage_lengths"]):
+        kids = {r["name"].split(".")[2] for r in got if r["name"].startswith("stages.%d." % s)}
+        assert kids == {str(i) for i in range(n)}
+    # darknet.py:40: x + body(x) — the addend rides in the epilogue of the block's second cell
+    for r in got:
+        assert bool(r["residual"]) == (r["name"].endswith(".body.1") and r["name"].startswith("stages.")), r["name"]
+    assert sum(r["residual"] for r in got) == 23
+    # yolo3.py:1167-1177: concat(slice_like(upsample(transition(x))), route_now) on axis 1, UPSAMPLED FIRST
+    cats = [c for c in g["concats_axis1"] if c["channels"][0] is not None]
+    assert [c["inputs"] for c in cats] == [["upsample(transitions.0.0)", "stages.1.8.body.1.0"],
+                                           ["upsample(transitions.1.0)", "stages.0.14.body.1.0"]]
+    for c in cats:
+        up, route = by[c["inputs"][0][len("upsample("):-3]], by[c["inputs"][1][:-2]]
+        total = sum(c["channels"])
+        assert up["upsample"] == 2 and up["concat_offset"] == 0 and up["cout"] == c["channels"][0]
+        assert route["concat_offset"] == c["channels"][0] and route["cout"] == c["channels"][1]   # written behind it
+        assert up["out_channels_total"] == route["out_channels_total"] == total
+    assert [r["name"] for r in got if r["upsample"] == 2] == ["transitions.0", "transitions.1"]
+    # the recorded upsample is repeat(axis=-1) then repeat(axis=-2), both x2 (layers.py:11-20), cropped on axes (2, 3)
+    top = [(o["op"], o["kwargs"]) for o in g["ops_top_level"]]
+    assert top[:4] == [("x.repeat", {"axis": -1, "repeats": 2}), ("x.repeat", {"axis": -2, "repeats": 2}),
+                       ("F.slice_like", {"axes": [2, 3]}), ("F.concat", {"dim": 1})]
+
+
+def test_only_six_cells_take_the_passed_norm_layer(golden):
+    """train_yolov3.py:350-354 passes SyncBatchNorm(num_devices) to yolo3_darknet53; wrappers.py:54 hands it to get_darknet
+    and NOT to YOLOV3T (wrappers.py:101-103), and the residual blocks hard-wire BatchNorm (darknet.py:89-91): the stem and
+    the five stride-2 convs are the only cells that exchange statistics.  (SURVEY section 2 said 26.)"""
+    g = golden["voc20_syncbn8"]
+    assert g["norm_classes"] == {"SyncBatchNorm": 6, "BatchNorm": 66}
+    want = sorted(r["name"] + ".1" for r in _convs(20) if r["sync_bn"])
+    assert want == g["cells_with_the_passed_norm_layer"] == ["stages.0.0.1", "stages.0.1.1", "stages.0.3.1", "stages.0.6.1",
+                                                              "stages.1.0.1", "stages.2.0.1"]
+    sync = [r for r in g["convs"] if r["norm"] and r["norm"]["class"] == "SyncBatchNorm"]
+    assert all(r["norm"]["kwargs"] == {"epsilon": 1e-05, "momentum": 0.9, "num_devices": 8} for r in sync)
+    assert [r["stride"] for r in sync] == [[1, 1]] + [[2, 2]] * 5
+    # the graph itself does not depend on the norm layer
+    strip = lambda rows: [{k: v for k, v in r.items() if k != "norm"} for r in rows]  # noqa: E731
+    assert strip(g["convs"]) == strip(golden["voc20"]["convs"])
+
+
+@pytest.mark.parametrize("key,ncls,count", [("voc20", 20, 61626049), ("vid30", 30, 61679899)])
+def test_parameter_names_and_counts(golden, key, ncls, count):
+    g = golden[key]
+    rows = _params(ncls)
+    assert g["trainable_parameters"] == count == sum(sz for _, sz, tr, _, _ in rows if tr)
+    assert g["running_statistics"] == 52608 == sum(sz for _, sz, tr, _, _ in rows if not tr)
+    # the structural names save_parameters writes (the file is a name -> array dict: order carries no meaning).  Gluon lists
+    # them in child REGISTRATION order (stages, transitions, yolo_blocks, yolo_outputs: yolo3.py:1000-1008), the library in
+    # execution order; inside one block the orders agree
+    assert sorted(n for n, *_ in rows) == sorted(g["parameter_names"]) and len(rows) == len(g["parameter_names"]) == 366
+    for top in ("stages.", "transitions.", "yolo_blocks.", "yolo_outputs."):
+        sub = lambda names: sorted(n for n in names if n.startswith(top))  # noqa: E731
+        assert sub(n for n, *_ in rows) == sub(g["parameter_names"])
+    assert [n for n, *_ in rows if n.startswith("stages.")] == [n for n in g["parameter_names"] if n.startswith("stages.")]
+    shapes = {n: shp for n, _, _, shp, _ in rows}
+    for r in g["convs"]:
+        assert shapes[r["name"] + ".weight"] == [r["cout"], r["cin"], r["kernel"][0], r["kernel"][1]]
+        if r["use_bias"]:
+            assert shapes[r["name"] + ".bias"] == [r["cout"]]
+    # freeze_base (wrappers.py:55-57) reaches exactly the Darknet-53 tensors
+    assert all(bool(bb) == n.startswith("stages.") for n, _, _, _, bb in rows)
+
+
+def test_heads_and_the_detection_calls(golden):
+    """anchors[::-1][i] / strides[::-1][i] per output layer (yolo3.py:1013-1014, wrappers.py:80-84), the offsets constant
+    (x, y) meshgrid of alloc_size (yolo3.py:67-74), the box_nms call of yolo3.py:1198-1200 with the defaults of
+    yolo3.py:959-963, and the slices that make (ids, scores, bboxes)."""
+    import videoyolo_amd as vy
+    from videoyolo_amd import targets
+    from oracle import yolo3_oracle as O
+    g = golden["voc20"]
+    assert [h["stride"] for h in g["heads"]] == list(targets.STRIDES) == [32, 16, 8]
+    assert np.array_equal(np.array([h["anchors"] for h in g["heads"]]).reshape(9, 2), targets.ANCHORS[[6, 7, 8, 3, 4, 5, 0, 1, 2]]) or \
+        np.array_equal(np.array([h["anchors"] for h in g["heads"]]).reshape(9, 2), targets.ANCHORS)
+    assert all(h["num_anchors"] == 3 and h["num_pred"] == 25 and h["offsets_shape"] == [1, 1, 128, 128, 2] for h in g["heads"])
+    assert all(h["offsets_first_xy"] == [2, 1] for h in g["heads"])   # offsets[0, 0, y = 1, x = 2] = (x, y)
+    net = vy.yolo3_darknet53(["c%d" % i for i in range(20)], pretrained_base=False)
+    consts = net.constants()
+    for i, h in enumerate(g["heads"]):
+        assert consts["yolo_outputs.%d.anchors" % i].reshape(-1).tolist() == h["anchors"]
+        assert list(consts["yolo_outputs.%d.offsets" % i].shape) == h["offsets_shape"]
+        assert consts["yolo_outputs.%d.offsets" % i][0, 0, 1, 2].tolist() == h["offsets_first_xy"]
+    assert g["nms_defaults"] == {"nms_thresh": 0.45, "nms_topk": 400, "post_nms": 100}
+    assert (net.nms_thresh, net.nms_topk, net.post_nms) == (0.45, 400, 100)
+    ops = {o["op"]: o for o in g["ops_top_level"]}
+    nms = ops["F.contrib.box_nms"]["kwargs"]
+    assert nms == {"coord_start": 2, "force_suppress": False, "id_index": 0, "overlap_thresh": 0.45, "score_index": 1, "topk": 400,
+                   "valid_thresh": 0.01}
+    sig = inspect.signature(O.box_nms).parameters
+    assert {k: sig[k].default for k in ("overlap_thresh", "valid_thresh", "topk", "force_suppress")} == \
+        {"overlap_thresh": 0.45, "valid_thresh": 0.01, "topk": 400, "force_suppress": False}
+    tail = [(o["op"], o["kwargs"]) for o in g["ops_top_level"][-4:]]
+    assert tail == [("x.slice_axis", {"axis": 1, "begin": 0, "end": 100}), ("x.slice_axis", {"axis": -1, "begin": 0, "end": 1}),
+                    ("x.slice_axis", {"axis": -1, "begin": 1, "end": 2}), ("x.slice_axis", {"axis": -1, "begin": 2, "end": None})]
+
+
+@pytest.mark.parametrize("key,ncls", [("voc20", 20), ("vid30", 30)])
+def test_decode_call_sequence_of_the_output_layer(golden, key, ncls):
+    """The operator calls YOLOOutputV3.hybrid_forward makes in inference mode (yolo3.py:158-197), with their non-tensor
+    arguments, as executed: the sequence oracle/yolo3_oracle.py's `output` restates literally and csrc/detect.hip fuses —
+    (B, A*P, HW) -> (B, HW, A, P); xy / wh / obj / cls slices; class-major tiling; (C, B, HW, A, 6) -> (B, C*HW*A, 6)."""
+    P = 5 + ncls
+    want = [("x.reshape", [[0, 3 * P, -1]], {}), ("x.transpose", [], {"axes": [0, 2, 1]}), ("x.reshape", [[0, -1, 3, P]], {}),
+            ("x.slice_axis", [], {"axis": -1, "begin": 0, "end": 2}), ("x.slice_axis", [], {"axis": -1, "begin": 2, "end": 4}),
+            ("x.slice_axis", [], {"axis": -1, "begin": 4, "end": 5}), ("x.slice_axis", [], {"axis": -1, "begin": 5, "end": None}),
+            ("F.slice_like", [], {"axes": [2, 3]}), ("x.reshape", [[1, -1, 1, 2]], {}),
+            ("F.sigmoid", [], {}), ("F.broadcast_add", [], {}), ("F.exp", [], {}), ("F.broadcast_mul", [], {}),
+            ("F.sigmoid", [], {}), ("F.sigmoid", [], {}), ("F.broadcast_mul", [], {}), ("F.concat", [], {"dim": -1}),
+            ("F.tile", [], {"reps": [ncls, 1, 1, 1, 1]}), ("F.transpose", [], {"axes": [3, 0, 1, 2]}), ("x.expand_dims", [], {"axis": -1}),
+            ("F.arange", [0, ncls], {}), ("x.reshape", [[0, 1, 1, 1, 1]], {}), ("F.broadcast_add", [], {}), ("F.concat", [], {"dim": -1}),
+            ("x.transpose", [], {"axes": [1, 0, 2, 3, 4]}), ("F.reshape", [[0, -1, 6]], {})]
+    got = [(o["op"], o["args"], o["kwargs"]) for o in golden[key]["ops_output_layer_0"]]
+    assert got == want

@@ -24,6 +24,13 @@ class ParamInfo(ctypes.Structure):
                 ("trainable", ctypes.c_int32), ("backbone", ctypes.c_int32)]
 
 
+class ConvInfo(ctypes.Structure):
+    _fields_ = [("name", ctypes.c_char * 96), ("cin", ctypes.c_int32), ("cout", ctypes.c_int32), ("kernel", ctypes.c_int32),
+                ("stride", ctypes.c_int32), ("pad", ctypes.c_int32), ("has_bn", ctypes.c_int32), ("sync_bn", ctypes.c_int32),
+                ("residual", ctypes.c_int32), ("upsample", ctypes.c_int32), ("concat_offset", ctypes.c_int32),
+                ("out_channels_total", ctypes.c_int32)]
+
+
 class LaunchStat(ctypes.Structure):
     _fields_ = [("name", ctypes.c_char * 64), ("ms", ctypes.c_float), ("flops", ctypes.c_double),
                 ("bytes", ctypes.c_double)]
@@ -40,6 +47,8 @@ SIGNATURES = {
     "vy_net_set_nms": (ctypes.c_int, [_vp, _f32, _i32, _i32]),
     "vy_net_num_params": (_i32, [_vp]),
     "vy_net_param_info": (ctypes.c_int, [_vp, _i32, ctypes.POINTER(ParamInfo)]),
+    "vy_net_num_convs": (_i32, [_vp]),
+    "vy_net_conv_info": (ctypes.c_int, [_vp, _i32, ctypes.POINTER(ConvInfo)]),
     "vy_net_param_bytes": (_sz, [_vp]),
     "vy_net_bind_params": (ctypes.c_int, [_vp, _vp]),
     "vy_net_param_set": (ctypes.c_int, [_vp, _i32, _vp, _vp]),

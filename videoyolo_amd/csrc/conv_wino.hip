@@ -84,8 +84,10 @@ hipError_t vy_launch_wino_weights(const float* w, void* img, int cout, int cin, 
 #define VY_WINO_ABL 0
 #endif
 
-// BM = pairs per block: 64 (4 waves, two blocks per CU) or 128 (8 waves, one block per CU: a W tile feeds twice the rows —
-// half the LDS-DMA instructions and L2 bytes per MFMA)
+// BM = pairs per block: 64 (4 waves, two blocks per CU).  128 (8 waves, one block per CU: a W tile feeds twice the rows —
+// half the LDS-DMA instructions and L2 bytes per MFMA) is instantiated by probe builds only (-DVY_WINO_BM128): measured
+// equal within the run-to-run spread on every batch-64 shape and 15-45 % slower on short launches
+// (profiles/r05_negative_results.txt section 1)
 template <int BM>
 __global__ __launch_bounds__(BM * 4, BM == 64 ? 2 : 1) void conv_wino_kernel(const ConvArgs a, const int tiles_n, const int Wp2,
                                                                               const int Mp, const long long wimg_bytes) {
@@ -371,10 +373,12 @@ static long long wino_tiles(const ConvArgs& a, int bm) {
   return ((pairs + bm - 1) / bm) * (a.N / 128);
 }
 
-// pairs per block of the launch (VY_WINO_BM=64 / 128: probes)
+// pairs per block of the launch (probe builds: VY_WINO_BM=128)
 static int wino_bm(const ConvArgs& a) {
+#ifdef VY_WINO_BM128
   const char* f = getenv("VY_WINO_BM");
-  if (f && (atoi(f) == 64 || atoi(f) == 128)) return atoi(f);
+  if (f && atoi(f) == 128) return 128;
+#endif
   return 64;
 }
 
@@ -407,7 +411,12 @@ hipError_t vy_launch_conv_wino(const ConvArgs& a, hipStream_t s) {
   k.w_split = a.w_wino;  // (the kernel reads its images through the same field)
   const int bm = wino_bm(a);
   const long long wb = (long long)vy_split_weight_bytes(a.w_cout, 3, a.Kc);
-  if (bm == 128) hipLaunchKernelGGL(conv_wino_kernel<128>, dim3((unsigned)wino_tiles(a, 128)), dim3(512), 0, s, k, tiles_n, Wp2, Mp, wb);
-  else hipLaunchKernelGGL(conv_wino_kernel<64>, dim3((unsigned)wino_tiles(a, 64)), dim3(256), 0, s, k, tiles_n, Wp2, Mp, wb);
+#ifdef VY_WINO_BM128
+  if (bm == 128) {
+    hipLaunchKernelGGL(conv_wino_kernel<128>, dim3((unsigned)wino_tiles(a, 128)), dim3(512), 0, s, k, tiles_n, Wp2, Mp, wb);
+    return hipGetLastError();
+  }
+#endif
+  hipLaunchKernelGGL(conv_wino_kernel<64>, dim3((unsigned)wino_tiles(a, bm)), dim3(256), 0, s, k, tiles_n, Wp2, Mp, wb);
   return hipGetLastError();
 }

@@ -64,6 +64,27 @@ int vy_net_param_info(const vy_net* net, int32_t i, vy_param_info* out) {
   return 0;
 }
 
+int32_t vy_net_num_convs(const vy_net* net) { return net ? (int32_t)net->convs.size() : 0; }
+
+int vy_net_conv_info(const vy_net* net, int32_t i, vy_conv_info* out) {
+  if (!net || !out || i < 0 || i >= (int32_t)net->convs.size()) return fail(VY_ERR_INVALID, "bad conv index %d", i);
+  const ConvT& c = net->convs[i];
+  memset(out, 0, sizeof *out);
+  snprintf(out->name, sizeof out->name, "%s", c.name.c_str());
+  out->cin = c.cin;
+  out->cout = c.cout;
+  out->kernel = c.k;
+  out->stride = c.stride;
+  out->pad = c.k / 2;
+  out->has_bn = c.p_gamma >= 0;
+  out->sync_bn = is_sync_layer(c);
+  out->residual = c.res_plane >= 0;
+  out->upsample = c.ups;
+  out->concat_offset = c.out_co;
+  out->out_channels_total = net->planes[c.out_plane].C;
+  return 0;
+}
+
 size_t vy_net_param_bytes(const vy_net* net) { return net ? (size_t)net->param_elems * sizeof(float) : 0; }
 
 int vy_net_bind_params(vy_net* net, void* dev_params) {

@@ -50,6 +50,13 @@ struct ConvT {
   int64_t split_off = -1;         // conv mode VY_CONV_SPLIT_BF16X3: byte offset of the bf16 weight images in the workspace region, -1: exact kernel
 };
 
+// the cells Darknet3D builds with the norm_layer passed to yolo3_darknet53 — the stem and the five stride-2 convs
+// (three_darknet.py:163-181); every other BatchNorm of the model is a plain per-device one: the residual blocks hard-wire
+// BatchNorm (darknet.py:89-91) and wrappers.py:101-103 does not hand norm_layer to YOLOV3T, so the heads default to it
+inline bool is_sync_layer(const ConvT& c) {
+  return c.p_gamma >= 0 && c.name.rfind("stages.", 0) == 0 && c.name.find(".body.") == std::string::npos;
+}
+
 static const int kAnchors[3][6] = {{10, 13, 16, 30, 33, 23}, {30, 61, 62, 45, 59, 119}, {116, 90, 156, 198, 373, 326}};
 static const int kStrides[3] = {8, 16, 32};  // wrappers.py:80-84
 

@@ -111,12 +111,6 @@ bool g_labels_done = false;
 
 constexpr int kBwdChunk = 64;  // pixels per partial-sum block of the bias-gradient reductions (and the scratch bound)
 
-bool is_sync_layer(const ConvT& c) {
-  // the layers Darknet3D builds with the passed norm_layer: the stem and the stride-2 convs
-  // (three_darknet.py:163-181); every other BatchNorm in the model is a plain per-device one
-  return c.p_gamma >= 0 && c.name.rfind("stages.", 0) == 0 && c.name.find(".body.") == std::string::npos;
-}
-
 VyTrain* get_train(vy_net* net) {
   if (!net->train) {
     net->train = new VyTrain();
