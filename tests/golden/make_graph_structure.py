@@ -55,11 +55,29 @@ class T:
             return T(self.c, self.tag)
         return method
 
+    def slice_axis(self, *a, **k):  # the tag remembers the slice: how the loss call's arguments are told apart
+        TRACE.op("x.slice_axis", a, k)
+        return T(self.c, "%s[%s:%s:%s]" % (self.tag, k.get("axis"), k.get("begin"), k.get("end")))
+
+    def _cmp(name):  # noqa: N805
+        def f(self, other):
+            TRACE.op("x." + name, (other,), {})
+            return T(self.c, "(%s %s %s)" % (self.tag, name, other.tag if isinstance(other, T) else other))
+        return f
+
+    __gt__, __lt__, __ge__, __le__ = _cmp(">"), _cmp("<"), _cmp(">="), _cmp("<=")
+
     def repeat(self, *a, **k):  # _upsample (layers.py:11-20): repeat on W, then H
         TRACE.op("x.repeat", a, k)
         return T(self.c, "upsample(%s)" % self.tag if not str(self.tag).startswith("upsample(") else self.tag)
 
-    __add__ = __radd__ = __sub__ = __rsub__ = __mul__ = __rmul__ = __truediv__ = __neg__ = _same
+    __add__ = __radd__ = __sub__ = __rsub__ = __rmul__ = __truediv__ = __neg__ = _same
+
+    def __mul__(self, other):  # (x * 0 is the reference's idiom for "a tensor shaped like x": the tag stays)
+        if isinstance(other, T):
+            return T(self.c, "(%s * %s)" % (self.tag, other.tag))
+        return T(self.c, self.tag if other == 0 or str(self.tag).startswith(("stages.", "yolo_", "transitions.", "upsample(", "concat", "input"))
+                 else "(%s * %s)" % (self.tag, other))
 
     def __iter__(self):
         raise TypeError("tensor stand-in is not iterable")
@@ -82,6 +100,7 @@ class Trace:
 
     def reset(self):
         self.ops, self.convs, self.norms, self.acts, self.concats, self.stack = [], [], [], [], [], []
+        self.misc = [m for m in getattr(self, "misc", []) if "ctor" in m]  # constructor records survive a reset
 
     def op(self, name, a, k):
         self.ops.append({"op": name, "in": self.stack[-1] if self.stack else "", "args": [_plain(v) for v in a if not isinstance(v, T)],
@@ -111,9 +130,16 @@ class FNamespace:
                 dim = k.get("dim", 1)
                 rec = {"in": TRACE.stack[-1] if TRACE.stack else "", "dim": dim, "channels": [t.c for t in ts], "inputs": [t.tag for t in ts]}
                 TRACE.concats.append(rec)
+                import re
+                tags = {re.sub(r"yolo_outputs\.\d\.prediction", "pred", str(t.tag)) for t in ts}  # the same slice of each scale
+                tag = tags.pop() if len(tags) == 1 else "concat"
                 if dim == 1 and all(t.c is not None for t in ts):
-                    return T(sum(t.c for t in ts), "concat")
-                return T(None, "concat")
+                    return T(sum(t.c for t in ts), tag)
+                return T(None, tag)
+            if name == "where":
+                return T(None, "where(%s ? %s : %s)" % tuple(t.tag for t in ts[:3]))
+            if name in ("zeros_like", "ones_like"):
+                return T(None, name[:-5])
             return T(ts[0].c, ts[0].tag) if ts else T(None)
         return fn
 
@@ -326,7 +352,29 @@ class _Autograd(types.ModuleType):
         return contextlib.nullcontext()
 
 
+class BBoxBatchIOU(HybridBlock):
+    def __init__(self, *a, **kw):
+        super().__init__()
+        TRACE.misc.append({"ctor": "BBoxBatchIOU", "args": [_plain(v) for v in a], "kwargs": {k: _plain(v) for k, v in kw.items()}})
+
+    def forward(self, a, b):
+        TRACE.op("BBoxBatchIOU()", (), {"a": a.tag, "b": b.tag})
+        return T(None, "batch_iou(%s, %s)" % (a.tag, b.tag))
+
+
+class YOLOV3Loss(HybridBlock):
+    def __init__(self, *a, **kw):
+        super().__init__()
+        TRACE.misc.append({"ctor": "YOLOV3Loss", "args": [_plain(v) for v in a], "kwargs": {k: _plain(v) for k, v in kw.items()}})
+
+    def forward(self, *args):
+        TRACE.misc.append({"call": "YOLOV3Loss", "arg_tags": [t.tag for t in args]})
+        return tuple(T(None, n) for n in ("obj_loss", "center_loss", "scale_loss", "cls_loss"))
+
+
 KNOWN = {
+    "gluoncv.nn.bbox": {"BBoxBatchIOU": BBoxBatchIOU},
+    "gluoncv.loss": {"YOLOV3Loss": YOLOV3Loss},
     "mxnet.gluon": {"Block": Block, "HybridBlock": HybridBlock},
     "mxnet.gluon.nn": {"Block": Block, "HybridBlock": HybridBlock, "HybridSequential": HybridSequential, "Sequential": Sequential,
                        "Conv2D": Conv2D, "BatchNorm": BatchNorm, "LeakyReLU": LeakyReLU},
@@ -412,6 +460,31 @@ def record(num_class, sync):
                       "num_pred": int(o._num_pred), "num_anchors": int(o._num_anchors),
                       "offsets_shape": list(np.asarray(o.offsets.value).shape),
                       "offsets_first_xy": np.asarray(o.offsets.value)[0, 0, 1, 2].tolist()})  # (y = 1, x = 2) -> [2, 1]
+    # ---- training: the recorded call (train_yolov3.py:623-626) and the train-mode non-recording call (transforms.py:192)
+    infer_ops_top, infer_ops_out0, infer_concats = TRACE.ops, None, TRACE.concats
+    infer_ops_out0 = [o for o in TRACE.ops if o["in"] == "yolo_outputs.0"]
+    infer_ops_top = [o for o in TRACE.ops if o["in"] == ""]
+    TRACE.reset()
+    mxnet.autograd.training, mxnet.autograd.recording = True, True
+    names = ("gt_boxes", "obj_t", "centers_t", "scales_t", "weights_t", "clas_t")
+    losses = net(T(3, "input"), *[T(None, n) for n in names])
+    loss_call = [m for m in TRACE.misc if m.get("call") == "YOLOV3Loss"]
+    train = {
+        "returns": [t.tag for t in losses],
+        "loss_call_arg_tags": loss_call[0]["arg_tags"],
+        "ignore_iou_thresh": net._target_generator._dynamic_target._ignore_iou_thresh,
+        "label_smooth_default": net._target_generator._label_smooth,
+        "ctor_records": [m for m in TRACE.misc if "ctor" in m][-2:],
+        "ops_target_merger": [o for o in TRACE.ops if o["in"] == "_target_generator"],
+        "ops_dynamic_target": [o for o in TRACE.ops if o["in"] == "_target_generator._dynamic_target"],
+        "ops_output_layer_0_train": [o for o in TRACE.ops if o["in"] == "yolo_outputs.0"],
+    }
+    TRACE.reset()
+    mxnet.autograd.training, mxnet.autograd.recording = True, False
+    tup = net(T(3, "input"))
+    train["train_mode_tuple"] = [([u.tag for u in t] if isinstance(t, list) else t.tag) for t in tup]
+    mxnet.autograd.training = mxnet.autograd.recording = False
+
     weights = sum(r["cout"] * r["cin"] * r["kernel"][0] * r["kernel"][1] // r["groups"] for r in rows)
     biases = sum(r["cout"] for r in rows if r["use_bias"])
     bn_ch = sum(n["channels"] for n in TRACE.norms)
@@ -422,15 +495,16 @@ def record(num_class, sync):
         "convs": rows,
         "stage_lengths": [len(s) for s in net.stages],
         "heads": heads,
-        "concats_axis1": [c for c in TRACE.concats if c["dim"] == 1 and c["in"] == ""],
+        "concats_axis1": [c for c in infer_concats if c["dim"] == 1 and c["in"] == ""],
         "cells_with_the_passed_norm_layer": sorted(n["name"] for n in TRACE.norms if n["class"] == "SyncBatchNorm"),
         "norm_classes": collections.Counter(n["class"] for n in TRACE.norms),
         "trainable_parameters": weights + biases + 2 * bn_ch,
         "running_statistics": 2 * bn_ch,
         "parameter_names": [k for k in params if not k.rsplit(".", 1)[-1].startswith(("anchor_", "offset_"))],
         "nms_defaults": {"nms_thresh": net.nms_thresh, "nms_topk": net.nms_topk, "post_nms": net.post_nms},
-        "ops_top_level": [o for o in TRACE.ops if o["in"] == ""],
-        "ops_output_layer_0": [o for o in TRACE.ops if o["in"] == "yolo_outputs.0"],
+        "ops_top_level": infer_ops_top,
+        "ops_output_layer_0": infer_ops_out0,
+        "train": train,
     }
 
 

@@ -212,3 +212,39 @@ def test_decode_call_sequence_of_the_output_layer(golden, key, ncls):
             ("x.transpose", [], {"axes": [1, 0, 2, 3, 4]}), ("F.reshape", [[0, -1, 6]], {})]
     got = [(o["op"], o["args"], o["kwargs"]) for o in golden[key]["ops_output_layer_0"]]
     assert got == want
+
+
+@pytest.mark.parametrize("key,ncls", [("voc20", 20), ("vid30", 30)])
+def test_training_call_structure(golden, key, ncls):
+    """The RECORDED call net(x, gt_boxes, obj_t, centers_t, scales_t, weights_t, clas_t) (train_yolov3.py:625) as the
+    reference executes it — which slice of the prediction goes to which argument of YOLOV3Loss (yolo3.py:1181-1187), what
+    the target merger selects (yolo_target.py:259-281) and the dynamic generator computes (yolo_target.py:193-205) — and
+    the 8-tuple of the train-mode non-recording call (yolo3.py:1189-1192).  Call structure only: what YOLOV3Loss and
+    BBoxBatchIOU compute is not in the tree and is not recorded."""
+    import videoyolo_amd as vy
+    from oracle import yolo3_train_oracle as TO
+    t = golden[key]["train"]
+    assert t["returns"] == ["obj_loss", "center_loss", "scale_loss", "cls_loss"]
+    assert t["loss_call_arg_tags"] == [
+        "pred[-1:4:5]", "pred[-1:0:2]", "pred[-1:2:4]", "pred[-1:5:None]",                       # objness, centers, scales, classes
+        "where((obj_t > 0) ? obj_t : ((batch_iou(pred[-1:0:2], gt_boxes) > 0.7) * -1))",       # ignore mask: -1 where max IoU > 0.7
+        "where((obj_t > 0) ? centers_t : zeros)", "where((obj_t > 0) ? scales_t : zeros)", "where((obj_t > 0) ? weights_t : zeros)",
+        "where((obj_t > 0) ? clas_t : (ones * -1))",
+        "((obj_t > 0) * (where((obj_t > 0) ? clas_t : (ones * -1)) >= 0))"]                     # class_mask
+    assert t["ctor_records"] == [{"ctor": "BBoxBatchIOU", "args": [], "kwargs": {}}, {"ctor": "YOLOV3Loss", "args": [], "kwargs": {}}]
+    assert t["ignore_iou_thresh"] == 0.7 and t["label_smooth_default"] is False
+    net = vy.yolo3_darknet53(["c%d" % i for i in range(ncls)], pretrained_base=False)
+    assert net._ignore_iou_thresh == 0.7 and net._target_generator._label_smooth is False
+    assert [(o["op"], o["args"], o["kwargs"]) for o in t["ops_dynamic_target"]][-2:] == \
+        [("x.max", [], {"axis": -1, "keepdims": True}), ("x.>", [0.7], {})]
+    merger = [(o["op"], o["args"], o["kwargs"]) for o in t["ops_target_merger"]]
+    assert merger[:10] == [("x.>", [0], {}), ("F.where", [], {}), ("x.tile", [], {"reps": [2]}), ("F.where", [], {}), ("F.where", [], {}),
+                           ("F.where", [], {}), ("x.tile", [], {"reps": [ncls]}), ("F.where", [], {}), ("x.tile", [], {"reps": [ncls]}),
+                           ("x.>=", [0], {})]
+    assert [m[0] for m in merger[10:]] == ["F.stop_gradient"] * 6
+    # the oracle's restatement takes the same arguments in the same order and returns the same six targets
+    assert list(inspect.signature(TO.OracleYolo3Train.merge_targets).parameters)[1:] == \
+        ["box_preds", "gt_boxes", "obj_t", "centers_t", "scales_t", "weights_t", "clas_t"]
+    # train-mode, not recording: (box_preds, [anchors] x 3, [offsets] x 3, [fake featmaps] x 3, centers, scales, objness, classes)
+    assert t["train_mode_tuple"] == ["pred[-1:0:2]", ["const:anchors"] * 3, ["const:offsets"] * 3, ["zeros"] * 3,
+                                     "pred[-1:0:2]", "pred[-1:2:4]", "pred[-1:4:5]", "pred[-1:5:None]"]
