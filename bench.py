@@ -48,6 +48,12 @@ FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 25
 BF16_MFMA_PEAK_TFLOPS = 2516.6  # v_mfma_f32_32x32x16_bf16: 16x the fp32 rate (same guide); the split path spends
 SPLIT_PRODUCTS = 6              # six bf16 products per fp32 multiply -> fp32-equivalent roof 2516.6 / 6 = 419.4
 HBM_PEAK_GBS = 8000.0
+# xGMI: 7 point-to-point links per GPU, ~153.6 GB/s each counting both directions (the task statement's figure) = 76.8 GB/s
+# per direction.  What an all-reduce of S bytes over N fully connected GPUs can reach:
+#   one ring over one link per neighbour          bus bandwidth <= 76.8 GB/s
+#   reduce-scatter + all-gather over ALL N - 1 links at once (each GPU sends S / N to every peer, twice)
+#                                                  bus bandwidth <= (N - 1) x 76.8 GB/s  (537.6 at N = 8)
+XGMI_LINK_GBPS_PER_DIRECTION = 76.8
 ROCPROF = "/opt/rocm/bin/rocprofv3"
 
 
@@ -332,6 +338,17 @@ def train_leg(vy, dev, dist, rank, world, size, batch, classes, steps, warmup, s
         out["allreduce_alone_ms"] = alone
         out["allreduce_bytes"] = nbytes
         out["allreduce_busbw_GBps"] = 2.0 * (world - 1) / world * nbytes / (alone * 1e-3) / 1e9
+        if world > 1:
+            all_links = (world - 1) * XGMI_LINK_GBPS_PER_DIRECTION
+            out["allreduce_expectation"] = {
+                "all_links_rs_ag_busbw_GBps": all_links, "single_ring_busbw_GBps": XGMI_LINK_GBPS_PER_DIRECTION,
+                "ms_at_all_links": 2.0 * (world - 1) / world * nbytes / (all_links * 1e9) * 1e3,
+                "ms_at_single_ring": 2.0 * (world - 1) / world * nbytes / (XGMI_LINK_GBPS_PER_DIRECTION * 1e9) * 1e3,
+                "frac_of_all_links": out["allreduce_busbw_GBps"] / all_links,
+                "note": "xGMI is point-to-point: %d links x %.1f GB/s per direction per GPU.  RCCL is left to choose (no NCCL_ALGO / "
+                        "NCCL_PROTO override): above the single-ring figure it is using several links at once; the bucketed "
+                        "all-reduce of the step hides behind backward either way (allreduce_overlap_fraction)"
+                        % (world - 1, XGMI_LINK_GBPS_PER_DIRECTION)}
         if world == 1:
             out["allreduce_note"] = "one rank (VY_FORCE_COLLECTIVES): the collective runs through the backend but moves nothing between devices"
         if split:
@@ -341,6 +358,73 @@ def train_leg(vy, dev, dist, rank, world, size, batch, classes, steps, warmup, s
     gc.collect()  # the net's ctypes callbacks hold a reference cycle: collect before returning its buffers
     torch.cuda.empty_cache()
     return out
+
+
+def host_fed_leg(vy, dev, dist, rank, world, size, batch, classes, steps, warmup, src_hw, conv_mode="exact", obj_bias=0.0,
+                 resident_fps=None):
+    """The reference's detect loop (detect_yolo3.py:209-233) fed from the HOST: per step one clip batch of world x batch
+    uint8 frames (src_hw, e.g. decoded 720p video) lies in host memory; every rank takes its slice
+    (parallel.scatter_frames, even_split=False sizes), copies it in on a copy stream, resizes + normalises it on the GPU
+    (csrc/preproc.hip, interp 9), runs the net, gathers the (B, 100, 6) rows of all ranks (RCCL all-gather; nothing at
+    N = 1) and rank 0 copies them to the host — double-buffered (videoyolo_amd/stream.py): batch i + 1 goes in and batch
+    i - 1 comes out while batch i computes.  Timed like the headline: warm-up batches, then exactly `steps` batches
+    between barrier + synchronize, max over ranks; every result has been collected on the host when the clock stops."""
+    import numpy as np
+    import torch
+    from videoyolo_amd import stream
+    net = vy.yolo3_darknet53(["c%d" % i for i in range(classes)], pretrained_base=False)
+    net.initialize(init="synthetic", seed=233, obj_bias=obj_bias)
+    net.collect_params().reset_ctx(dev)
+    net.set_nms(0.45, 400, 100)
+    net.set_conv_mode(conv_mode)
+    h, w = src_hw
+    gb = batch * world
+    rng = np.random.default_rng(77)
+    clips = [rng.integers(0, 256, (gb, h, w, 3), dtype=np.uint8) for _ in range(2)]  # the same clip batches on every rank
+    det = stream.HostFedDetector(net, gb, (h, w), size, depth=2, gather=True)
+    kept = 0
+    for i, out in enumerate(det.run(clips[i & 1] for i in range(warmup))):
+        pass
+    _barrier(dist, torch)
+    t0 = time.perf_counter()
+    for out in det.run(clips[i & 1] for i in range(steps)):
+        if out is not None:
+            kept = int((out[0] >= 0).sum())
+    _barrier(dist, torch)
+    dt = _max_over_ranks(time.perf_counter() - t0, dist, torch, dev)
+    fps = gb * steps / dt
+    # the copies alone, on an idle GPU (this rank's slice in, the gathered rows out)
+    e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+    cin, cout = [], []
+    for _ in range(4):
+        torch.cuda.synchronize()
+        e0.record()
+        det.dev_in[0].copy_(det.pin_in[0], non_blocking=True)
+        e1.record()
+        det.pin_out[0].copy_(det.dev_out[0], non_blocking=True)
+        e2.record()
+        torch.cuda.synchronize()
+        cin.append(e0.elapsed_time(e1))
+        cout.append(e1.elapsed_time(e2))
+    leg = {"frames_per_s": fps, "ms_per_step": 1e3 * dt / steps, "n_gpus": world, "per_gpu_batch": batch, "global_batch": gb,
+           "size": size, "classes": classes, "steps": steps, "warmup": warmup, "source_frames": "%dx%d uint8 (HWC)" % (h, w),
+           "dtype": "f32" if conv_mode == "exact" else SPLIT_DTYPE, "kept_detections_last_batch": kept,
+           "copy_in_alone_ms": sorted(cin)[len(cin) // 2], "copy_in_bytes": int(det.pin_in[0].numel()),
+           "copy_in_GBps": det.pin_in[0].numel() / (sorted(cin)[len(cin) // 2] * 1e-3) / 1e9,
+           "copy_out_alone_ms": sorted(cout)[len(cout) // 2], "copy_out_bytes": int(det.pin_out[0].numel() * 4),
+           "pipeline": "pinned host uint8 -> H2D (copy stream) -> resize + to_tensor + normalise -> net -> %s-> D2H (copy stream); "
+                       "2 slots" % ("all-gather of the rows over %s " % (dist.get_backend() if dist is not None else "-") if world > 1 else "")}
+    if resident_fps:
+        # what feeding from the host costs per step beyond the resident step (pre-processing kernel + whatever of the copies
+        # and of the host-side staging does not hide behind the previous batch's kernels)
+        leg["resident_frames_per_s"] = resident_fps
+        leg["vs_resident"] = fps / resident_fps
+        leg["exposed_ms_per_step"] = 1e3 * dt / steps - 1e3 * gb / resident_fps
+    del det, net
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()
+    return leg
 
 
 def torch_cpu_baseline(params, x, classes):
@@ -403,6 +487,8 @@ def main():
     ap.add_argument("--obj-bias", type=float, default=0.0,
                     help="added to the objectness biases (-5: trained-like sparse candidates)")
     ap.add_argument("--cpu-frames", type=int, default=4, help="frames of the CPU-oracle sample (0: skip)")
+    ap.add_argument("--cpu-torch-frames", type=int, default=32,
+                    help="frames of the torch-CPU datapoint (one batch: the host's cores need a batch this size to be busy)")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--mode", choices=["infer", "train"], default="infer",
                     help="infer: BASELINE configs[1] headline + the training legs (default); train: configs[2] as the "
@@ -425,6 +511,10 @@ def main():
     ap.add_argument("--no-split-leg", action="store_true", help="skip also_infer608_split")
     ap.add_argument("--no-train-legs", action="store_true",
                     help="infer mode: skip also_train416 / also_syncbn608 (BASELINE configs[2] / [4])")
+    ap.add_argument("--no-host-legs", action="store_true", help="skip also_hostfed608 / also_vid608 (host-fed pipelined legs)")
+    ap.add_argument("--src-hw", default="720x1280", help="also_hostfed608: size of the uint8 source frames (HxW)")
+    ap.add_argument("--vid-src-hw", default="360x640", help="also_vid608: size of the uint8 source frames (HxW)")
+    ap.add_argument("--vid-batch", type=int, default=64, help="also_vid608: frames per GPU and clip batch")
     ap.add_argument("--train-steps", type=int, default=10, help="timed steps of each training leg")
     ap.add_argument("--train-size", type=int, default=416)
     ap.add_argument("--train-batch", type=int, default=16, help="frames per GPU of also_train416")
@@ -459,7 +549,7 @@ def main():
     in_child = bool(os.environ.get("VY_BENCH_CHILD"))
     if args.gpus == 1 and "WORLD_SIZE" not in os.environ and not in_child and not args.no_pmc and not args.no_roofline:
         quiet = ["--steps", "2", "--warmup", "1", "--cpu-frames", "0", "--no-roofline", "--no-pmc", "--no-latency",
-                 "--no-train-legs"]
+                 "--no-train-legs", "--no-host-legs"]
         child = ["--mode", args.mode, "--size", str(args.size), "--batch", str(args.batch), "--classes",
                  str(args.classes), "--obj-bias", str(args.obj_bias), "--no-split-leg"] + quiet
         traffic, traffic_note = measure_hbm_traffic(child + ["--conv-mode", args.conv_mode], 3)
@@ -537,7 +627,8 @@ def main():
         med, agg = launch_table(net, x)
         # the dominant kernel: the implicit-GEMM tile variant with the largest share of the step
         # (128x128 at the BASELINE shape; small test shapes fall back to the smaller tiles)
-        dom = max((k for k in agg if k.startswith(("conv_igemm_kernel", "conv_split_kernel"))), key=lambda k: agg[k][1])
+        conv_prefixes = ("conv_igemm_kernel", "conv_split_kernel", "conv_wino_kernel")  # (the last two only with --conv-mode split_bf16x3)
+        dom = max((k for k in agg if k.startswith(conv_prefixes)), key=lambda k: agg[k][1])
         n, ms, fl, by = agg[dom]
         achieved = fl / (ms * 1e-3) / 1e12
         total_ms = sum(a[1] for a in agg.values())
@@ -553,7 +644,7 @@ def main():
         result["roofline"]["algorithmic_bytes_per_launch_avg"] = by / n
         # Comparable across rounds whatever the "dominant" instance is (it changed identity in round 3, when stream-K
         # split the 128x128 launches into two kernels): EVERY conv launch of the step, sum of FLOPs / sum of time.
-        conv = [a for k, a in agg.items() if k.startswith(("conv_igemm_kernel", "conv_split_kernel"))]
+        conv = [a for k, a in agg.items() if k.startswith(conv_prefixes)]
         conv_ms, conv_fl = sum(a[1] for a in conv), sum(a[2] for a in conv)
         result["roofline"]["frac_all_conv"] = conv_fl / (conv_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS
         result["roofline"]["all_conv"] = {"launches_per_step": sum(a[0] for a in conv), "ms_per_step": conv_ms,
@@ -701,15 +792,35 @@ def main():
             "sample": "%d frames of the same %dx%d batch through oracle/ (C + OpenMP conv, numpy graph, "
                       "C NMS); MXNet itself is not installable here" % (args.cpu_frames, args.size, args.size)}
         try:
-            tdt = torch_cpu_baseline(params, xs, args.classes)
+            nt = max(1, min(args.cpu_torch_frames, args.batch))
+            tdt = torch_cpu_baseline(params, x[:nt].cpu().numpy(), args.classes)
             result["cpu_baseline_torch"] = {
-                "value": args.cpu_frames / tdt, "unit": "frames/s", "cores": int(torch.get_num_threads()),
-                "kind": "independent", "sample": "the same %d frames through torch-CPU conv2d / batch_norm / leaky_relu of the "
-                "same 75-conv graph (no decode / NMS); an independent CPU datapoint, NOT MXNet and not the checker"
-                % args.cpu_frames}
+                "value": nt / tdt, "unit": "frames/s", "cores": int(torch.get_num_threads()),
+                "kind": "independent", "sample": "%d frames of the same batch, as ONE batch, through torch-CPU conv2d / batch_norm / "
+                "leaky_relu of the same 75-conv graph (no decode / NMS); an independent CPU datapoint, NOT MXNet and not the checker"
+                % nt}
         except Exception as e:  # a second datapoint: never fail the line for it
             result["cpu_baseline_torch"] = {"value": None, "note": "%s: %s" % (type(e).__name__, e)}
         del orc, params
+
+    if not args.no_host_legs:
+        # host-fed, pipelined legs (every rank enters: the gather is a collective).  They build their own nets: release the
+        # resident batch first
+        hw = lambda t: tuple(int(v) for v in t.lower().split("x"))  # noqa: E731
+        del x, out
+        torch.cuda.empty_cache()
+        result["also_hostfed%d" % args.size] = dict(
+            host_fed_leg(vy, dev, dist, rank, world, args.size, args.batch, args.classes, args.steps, args.warmup, hw(args.src_hw),
+                         conv_mode=args.conv_mode, obj_bias=args.obj_bias, resident_fps=fps),
+            workload="the headline step fed from the host: decoded %s uint8 frames in pinned host memory instead of a resident "
+                     "fp32 batch (detect_yolo3.py:209-233, transforms.py:316-350)" % args.src_hw)
+        result["also_vid608"] = dict(
+            host_fed_leg(vy, dev, dist, rank, world, 608, args.vid_batch, 30, args.steps, args.warmup, hw(args.vid_src_hw),
+                         conv_mode=args.conv_mode),
+            workload="BASELINE.json configs[3]: ImageNet-VID-shape stream (30 classes), 608x608, one host clip batch of %d x %d "
+                     "frames (%s uint8) per step -> parallel.scatter_frames -> net -> parallel.gather_detections -> host"
+                     % (world, args.vid_batch, args.vid_src_hw))
+        x = out = None
 
     if legs:
         # BASELINE configs[2] (and [4] when N > 1) on the same ranks, timed the same way: all ranks enter.

@@ -5,7 +5,7 @@ library, so the two switch positions need two processes.
 With a third argument "graph" the net is hybridized BEFORE its first forward — the capture is then the first time the
 library sees these launches (its once-per-instance occupancy queries run inside the capture) — and only the inference
 digest is produced, from two replays.
-"infer" as the third argument stops after the inference digest (tools/sk_sweep.py).
+"infer" as the third argument stops after the inference digest (tools/archive/sk_sweep.py).
 usage: python sk_digest_worker.py SIZE BATCH [graph|infer]"""
 import hashlib
 import json

@@ -347,7 +347,7 @@ def test_split_training_step_within_the_steps_own_sensitivity(C, B, S, capsys):
     kink: ~25 per million activations) and every ignore-mask decision comes out the same.  Any forward that differs in
     the last bits flips a few of them, each flip changes a local gradient by 90 %, and the change spreads upstream: the
     EXACT path itself, fed the same frames scaled by (1 + 2^-22), moves its own parameter gradients by 1-2e-2 in relative
-    L2 and ~1e-1 of a tensor's max (measured: tools/dbg_split_train.py).  So: the split step's distance to the oracle must
+    L2 and ~1e-1 of a tensor's max (measured: tools/archive/dbg_split_train.py).  So: the split step's distance to the oracle must
     stay within 3x the distance the exact path's own one-ulp-perturbed step has — per tensor class, in relative L2."""
     import videoyolo_amd as vy
     from oracle import yolo3_train_oracle as TO
@@ -404,6 +404,46 @@ def test_split_gradients_alone_meet_the_exact_bars(which, env):
     import json
     r = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("RESULT ")][-1][7:])
     assert r["worst"] < 2e-3, (which, r)
+
+
+def test_split_gradients_under_the_products_routing_at_a_realistic_shape(tmp_path):
+    """the tight gradient bar used to be applied only with VY_SPLIT_ALWAYS=1 on shapes of at most 96 pixels.
+    Here the PRODUCT's cost-model routing decides (no VY_SPLIT_ALWAYS) at 416 x 416, 8 frames, 20 classes: forward exact
+    (VY_SPLIT_TRAIN=3: bit-equal activations, no branch flips), data gradients and weight gradients on the split kernels
+    wherever the models send them — and the step's label log (VY_TRAIN_LABELS, '# via' lines) must show that the launches
+    this is about really ran: data gradients on the 256 x 64 tile and data gradients as k-split launches.  Reference: the
+    same step in the exact mode on the GPU (itself held to the oracle by tests/test_gpu_fullsize.py); bar: every gradient
+    within 2e-3 of its tensor's maximum, as for the exact path against the oracle."""
+    import json
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    labels = str(tmp_path / "labels.txt")
+    code = (
+        "import sys, json; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import numpy as np\n"
+        "import test_gpu_split as t\n"
+        "C, B, S = 20, 8, 416\n"
+        "params, x, gt, tg = t._train_case(C, B, S)\n"
+        "cls = ['c%%d' %% i for i in range(C)]\n"
+        "ls, gs = t._step(t._net(cls, params, mode='split_bf16x3_train'), x, gt, tg)\n"   # first step of the process: the one the label log covers
+        "le, ge = t._step(t._net(cls, params, mode='exact'), x, gt, tg)\n"
+        "assert all(np.array_equal(a, b) for a, b in zip(ls, le)), 'forward is exact in both: the losses must be bit-equal'\n"
+        "worst = max((float(np.abs(gs[k] - ge[k]).max() / (np.abs(ge[k]).max() + 1e-6)), k) for k in ge)\n"
+        "differ = sum(1 for k in ge if not np.array_equal(gs[k], ge[k]))\n"
+        "print('RESULT', json.dumps({'worst': worst[0], 'where': worst[1], 'differ': differ, 'n': len(ge)}))\n") % (here, os.path.dirname(here))
+    env = {k: v for k, v in os.environ.items() if k != "VY_SPLIT_ALWAYS"}
+    env.update(VY_SPLIT_TRAIN="3", VY_SPLIT_WGRAD="1", VY_TRAIN_LABELS=labels)
+    p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=1500)
+    assert p.returncode == 0, p.stderr[-3000:]
+    r = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("RESULT ")][-1][7:])
+    lines = open(labels).read().splitlines()
+    via_dgrad = [lines[i + 1] for i, ln in enumerate(lines[:-1]) if ln.startswith("dgrad ") and lines[i + 1].startswith("# via")]
+    assert any(v.startswith("# via split 256x64") for v in via_dgrad), "no data gradient ran on the 256x64 split tile"
+    assert any(v.startswith("# via split") and int(v.rsplit("k", 1)[1]) > 1 for v in via_dgrad), "no data gradient ran as a k-split launch"
+    assert any(v == "# via exact" for v in via_dgrad)          # the routing really is per launch
+    assert r["differ"] > r["n"] // 2, r                          # the split kernels did produce the gradients
+    assert r["worst"] < 2e-3, r
 
 
 def test_split_training_equals_exact_training_when_switched_off(voc_classes, synth20, monkeypatch):

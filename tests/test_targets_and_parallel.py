@@ -74,6 +74,18 @@ ids = torch.full((len(mine), 5, 1), float(r)); sc = torch.ones(len(mine), 5, 1);
 gi, gs, gb = parallel.gather_detections(ids, sc, bb)
 assert gi.shape == (7, 5, 1) and gb.shape == (7, 5, 4)
 assert gi[:4].eq(0).all() and gi[4:].eq(1).all()
+# ... the same with the batch size known (no host-side size exchange: the pipelined loop's form), uneven and even slices
+gi2, gs2, gb2 = parallel.gather_detections(ids, sc, bb, total=7)
+assert torch.equal(gi2, gi) and torch.equal(gs2, gs) and torch.equal(gb2, gb)
+e_ids = torch.arange(3 * 5, dtype=torch.float32).reshape(3, 5, 1) + 100 * r
+ei, es, eb = parallel.gather_detections(e_ids, sc[:3] * (r + 1), bb[:3] + r, total=6)
+assert ei.shape == (6, 5, 1) and torch.equal(ei[:3], e_ids - 100 * r) and torch.equal(ei[3:], e_ids - 100 * r + 100)
+assert es[:3].eq(1).all() and es[3:].eq(2).all() and eb[:3].eq(0).all() and eb[3:].eq(1).all()
+try:
+    parallel.gather_detections(e_ids, sc[:3], bb[:3], total=8)   # every rank would hold 4 of 8: refused before any collective
+    raise SystemExit("a slice that does not match `total` was accepted")
+except ValueError:
+    pass
 torch.distributed.barrier()
 print("rank", r, "ok")
 """

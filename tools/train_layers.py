@@ -8,6 +8,8 @@ idx = [i for i, r in enumerate(rows) if r['Kernel_Name'].startswith('sgd_kernel'
 step = rows[idx[-2] + 1: idx[-1] + 1]
 labels = collections.defaultdict(list)
 for line in open(sys.argv[2]):
+    if line.startswith("#"):
+        continue
     kind, name, fl, m, n, k = line.split()
     labels[kind].append((name, float(fl), int(float(m)), int(float(n)), int(float(k))))
 dur = lambda r: (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3

@@ -633,9 +633,13 @@ static long long split_max_ksplit(const ConvArgs& a) {
 
 void vy_conv_split_cfg(const ConvArgs& a, int* bm, int* bn, int* ksplit) {
   static const char* force = getenv("VY_SPLIT_FORCE");  // experiments: VY_SPLIT_FORCE=128x64 or 128x64x4 (k-split)
-  int fks = 1;
-  if (force && sscanf(force, "%dx%dx%d", bm, bn, &fks) >= 2 && a.N % *bn == 0) {
-    *ksplit = (int)std::min<long long>(std::max(1, fks), split_max_ksplit(a));
+  int fks = 1, fbm = 0, fbn = 0;
+  if (force && sscanf(force, "%dx%dx%d", &fbm, &fbn, &fks) >= 2 && a.N % fbn == 0 &&
+      ((fbm == 128 && (fbn == 128 || fbn == 64)) || (fbm == 256 && fbn == 64))) {  // the three instantiated tiles only
+    // a slice is at least 6 k-steps of 16 channels (the kernel's prologue assumes a slice has work: T >= 1)
+    const long long t_all = (long long)a.ntaps * (a.Kc >> 4);
+    *bm = fbm, *bn = fbn;
+    *ksplit = (int)std::max<long long>(1, std::min<long long>(std::min<long long>(std::max(1, fks), split_max_ksplit(a)), t_all / 6));
     return;
   }
   vy_predict_split(a.M, a.N, (double)a.ntaps * a.Kc, (int)std::min<long long>(split_max_ksplit(a), 64), bm, bn, ksplit, vy_cu_count());

@@ -99,6 +99,11 @@ struct LabelLog {
   void note(const char* kind, const std::string& name, double M, double N, double K) {
     if (open_once()) fprintf(f, "%s %s %.0f %.0f %.0f %.0f\n", kind, name.c_str(), 2.0 * M * N * K, M, N, K);
   }
+  // "# via split 128x128 k2" / "# via exact": which kernel the preceding fwd / dgrad line went to (tests assert that the
+  // launches they mean to cover really ran; tools/train_layers.py skips '#' lines)
+  void via(const char* text) {
+    if (f) fprintf(f, "# via %s\n", text);
+  }
   void close_step() {
     if (f) {
       fclose(f);
@@ -387,8 +392,16 @@ int refresh_split_images(const TrainCtx& c) {
 // weight images (a.w_split) and the cost model predicts a gain; the exact kernel otherwise
 static int launch_conv(const ConvArgs& a, hipStream_t s) {
   if (a.w_split && vy_conv_split_pays(a)) {
+    if (!g_labels_done && g_labels.f) {
+      int bm, bn, ks;
+      char t[64];
+      vy_conv_split_cfg(a, &bm, &bn, &ks);
+      snprintf(t, sizeof t, "split %dx%d k%d", bm, bn, ks);
+      g_labels.via(t);
+    }
     HIP_TRY(vy_launch_conv_split(a, s));
   } else {
+    if (!g_labels_done && g_labels.f) g_labels.via("exact");
     HIP_TRY(vy_launch_conv_igemm(a, s));
   }
   return 0;

@@ -152,7 +152,7 @@ class YOLOV3(object):
         # batches at least this large run as two half-batches on two streams (two hardware queues);
         # 0 (default) disables.  Round 1: 838 vs 828 frames/s at 608x608 batch 64 (+1.2 %, +2.6 % at 416x416), the
         # second stream filling partly filled rounds.  Round 3, with those launches running as stream-K: 972 vs 984
-        # (-1.2 %), 1990 vs 2049 at 416x416 (tools/ab_two_stream.sh) — the holes are gone, the halves only cost
+        # (-1.2 %), 1990 vs 2049 at 416x416 (tools/archive/ab_two_stream.sh) — the holes are gone, the halves only cost
         self.two_stream_batch = int(os.environ.get("VY_TWO_STREAM_BATCH", "0"))
         self._twin = None
         _lib.check(self._lib.vy_net_set_nms(self._h, nms_thresh, nms_topk, post_nms))
@@ -447,7 +447,10 @@ class YOLOV3(object):
         self._graphs = {}
         tw = getattr(self, "_twin", None)
         if tw is not None:
-            _lib.check(self._lib.vy_net_set_conv_mode(tw["h"], modes[mode]))
+            # the twin never trains: any split mode is the inference one there, as at its creation (detect_two_streams) —
+            # its mode must not depend on whether set_conv_mode or the first two-stream call came first
+            twin_mode = _lib.VY_CONV_EXACT_FP32 if mode == "exact" else _lib.VY_CONV_SPLIT_BF16X3
+            _lib.check(self._lib.vy_net_set_conv_mode(tw["h"], twin_mode))
             tw["plan"] = None
 
     def set_nms(self, nms_thresh=0.45, nms_topk=400, post_nms=100):

@@ -222,21 +222,33 @@ def sync_replicas_if_any_dirty(net, src=0):
     return False
 
 
-def gather_detections(ids, scores, bboxes):
-    """Host gather of per-rank (B_r,100,·) results to rank 0 (detect_yolo3.py:233 as_numpy concat)."""
+def gather_detections(ids, scores, bboxes, total=None):
+    """Gather of per-rank (B_r, R, .) results (detect_yolo3.py:233 as_numpy concat): every rank gets the rows of the whole
+    batch, in rank order.  ``total`` = frames of the whole batch when the caller knows it (the slices are then
+    ``split_sizes(total, world)``, as ``scatter_frames`` cut them): no host-side size exchange, nothing waits for the
+    GPU — the form a pipelined loop needs (videoyolo_amd/stream.py).  Without it the sizes are exchanged first."""
     import torch
     if not is_initialized() or world_size() == 1:
         return ids, scores, bboxes
     dist = _dist()
+    w, r = world_size(), rank()
     packed = torch.cat([ids, scores, bboxes], dim=-1).contiguous()
-    sizes = [None] * world_size()
-    dist.all_gather_object(sizes, int(packed.shape[0]))
-    outs = [torch.empty((s,) + tuple(packed.shape[1:]), dtype=packed.dtype, device=packed.device) for s in sizes]
-    dist.all_gather(outs, packed) if len(set(sizes)) == 1 else [
-        dist.broadcast(outs[i] if i != rank() else packed, src=i) for i in range(world_size())]
-    if len(set(sizes)) != 1:
-        outs[rank()] = packed
-    full = torch.cat(outs, 0)
+    if total is not None:
+        sizes = split_sizes(int(total), w)
+        if sizes[r] != int(packed.shape[0]):
+            raise ValueError("rank %d holds %d frames of a batch of %d, expected %d" % (r, packed.shape[0], total, sizes[r]))
+    else:
+        sizes = [None] * w
+        dist.all_gather_object(sizes, int(packed.shape[0]))
+    if len(set(sizes)) == 1:
+        full = torch.empty((w * sizes[0],) + tuple(packed.shape[1:]), dtype=packed.dtype, device=packed.device)
+        dist.all_gather(list(full.split(sizes[0], 0)), packed)   # (views of one buffer: RCCL gathers in place)
+    else:  # even_split=False with a remainder: one broadcast per rank
+        outs = [packed if i == r else torch.empty((s,) + tuple(packed.shape[1:]), dtype=packed.dtype, device=packed.device)
+                for i, s in enumerate(sizes)]
+        for i in range(w):
+            dist.broadcast(outs[i], src=i)
+        full = torch.cat(outs, 0)
     return full[..., 0:1], full[..., 1:2], full[..., 2:]
 
 
