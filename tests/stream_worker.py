@@ -44,10 +44,11 @@ def main():
     net.collect_params().reset_ctx(dev)
     net.set_nms(0.45, 400, 100)
     det = stream.HostFedDetector(net, args.global_batch, (60, 80), args.size, depth=2, gather=True)
-    outs = list(det.run(clip_batches(args.batches, args.global_batch, 60, 80)))
+    # (copies: a result is a view of its slot's pinned buffer, valid until the slot is submitted again)
+    outs = [None if o is None else [np.array(a) for a in o] for o in det.run(clip_batches(args.batches, args.global_batch, 60, 80))]
     if rank == 0:
         np.savez(os.path.join(args.outdir, "gathered.npz"),
-                 **{"%s%d" % (n, i): np.array(o[j]) for i, o in enumerate(outs) for j, n in enumerate(("ids", "scores", "bboxes"))})
+                 **{"%s%d" % (n, i): o[j] for i, o in enumerate(outs) for j, n in enumerate(("ids", "scores", "bboxes"))})
     else:
         assert all(o is None for o in outs)
     dist.barrier()

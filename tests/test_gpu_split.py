@@ -408,7 +408,7 @@ def test_split_gradients_alone_meet_the_exact_bars(which, env):
 
 def test_split_gradients_under_the_products_routing_at_a_realistic_shape(tmp_path):
     """the tight gradient bar used to be applied only with VY_SPLIT_ALWAYS=1 on shapes of at most 96 pixels.
-    Here the PRODUCT's cost-model routing decides (no VY_SPLIT_ALWAYS) at 416 x 416, 8 frames, 20 classes: forward exact
+    Here the PRODUCT's cost-model routing decides (no VY_SPLIT_ALWAYS) at 416 x 416, 16 frames, 20 classes (BASELINE configs[2] per GPU): forward exact
     (VY_SPLIT_TRAIN=3: bit-equal activations, no branch flips), data gradients and weight gradients on the split kernels
     wherever the models send them — and the step's label log (VY_TRAIN_LABELS, '# via' lines) must show that the launches
     this is about really ran: data gradients on the 256 x 64 tile and data gradients as k-split launches.  Reference: the
@@ -423,7 +423,7 @@ def test_split_gradients_under_the_products_routing_at_a_realistic_shape(tmp_pat
         "import sys, json; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
         "import numpy as np\n"
         "import test_gpu_split as t\n"
-        "C, B, S = 20, 8, 416\n"
+        "C, B, S = 20, 16, 416\n"
         "params, x, gt, tg = t._train_case(C, B, S)\n"
         "cls = ['c%%d' %% i for i in range(C)]\n"
         "ls, gs = t._step(t._net(cls, params, mode='split_bf16x3_train'), x, gt, tg)\n"   # first step of the process: the one the label log covers
@@ -488,7 +488,8 @@ def test_recorded_forward_then_inference_keeps_the_winograd_images(voc_classes, 
     assert any("wino" in n for n in _split_launches(net, x)), "no Winograd launch in the inference pass"
     got = [t.cpu().numpy() for t in net(x, return_index=True)]
     heads = [net.read_head(i).cpu().numpy() for i in range(3)]
-    fresh = _net(voc_classes, params, mode="split_bf16x3")
+    # (the recorded forward moved the running statistics: the fresh net gets the parameters as they are NOW)
+    fresh = _net(voc_classes, {p.name: p.data() for p in net.collect_params().values()}, mode="split_bf16x3")
     want = [t.cpu().numpy() for t in fresh(x, return_index=True)]
     for i in range(3):
         assert np.array_equal(heads[i], fresh.read_head(i).cpu().numpy()), "head %d differs after a recorded forward" % i
