@@ -380,7 +380,10 @@ def host_fed_leg(vy, dev, dist, rank, world, size, batch, classes, steps, warmup
     h, w = src_hw
     gb = batch * world
     rng = np.random.default_rng(77)
-    clips = [rng.integers(0, 256, (gb, h, w, 3), dtype=np.uint8) for _ in range(2)]  # the same clip batches on every rank
+    # the same clip batches on every rank (a shared decoder / file; a rank touches only its slice); two distinct ones at
+    # N = 1, one at N > 1 (every rank process holds the WHOLE clip batch in host memory: 1.4 GB of 720p frames at N = 8)
+    clips = [rng.integers(0, 256, (gb, h, w, 3), dtype=np.uint8) for _ in range(2 if world == 1 else 1)]
+    clips = clips * 2
     det = stream.HostFedDetector(net, gb, (h, w), size, depth=2, gather=True)
     kept = 0
     for i, out in enumerate(det.run(clips[i & 1] for i in range(warmup))):
@@ -413,7 +416,7 @@ def host_fed_leg(vy, dev, dist, rank, world, size, batch, classes, steps, warmup
            "copy_in_GBps": det.pin_in[0].numel() / (sorted(cin)[len(cin) // 2] * 1e-3) / 1e9,
            "copy_out_alone_ms": sorted(cout)[len(cout) // 2], "copy_out_bytes": int(det.pin_out[0].numel() * 4),
            "pipeline": "pinned host uint8 -> H2D (copy stream) -> resize + to_tensor + normalise -> net -> %s-> D2H (copy stream); "
-                       "2 slots" % ("all-gather of the rows over %s " % (dist.get_backend() if dist is not None else "-") if world > 1 else "")}
+                       "2 slots" % ("all-gather of the rows over %s " % dist.get_backend() if det.gather else "")}
     if resident_fps:
         # what feeding from the host costs per step beyond the resident step (pre-processing kernel + whatever of the copies
         # and of the host-side staging does not hide behind the previous batch's kernels)
@@ -515,6 +518,7 @@ def main():
     ap.add_argument("--src-hw", default="720x1280", help="also_hostfed608: size of the uint8 source frames (HxW)")
     ap.add_argument("--vid-src-hw", default="360x640", help="also_vid608: size of the uint8 source frames (HxW)")
     ap.add_argument("--vid-batch", type=int, default=64, help="also_vid608: frames per GPU and clip batch")
+    ap.add_argument("--vid-size", type=int, default=608, help="also_vid608: network input size (tests use small ones)")
     ap.add_argument("--train-steps", type=int, default=10, help="timed steps of each training leg")
     ap.add_argument("--train-size", type=int, default=416)
     ap.add_argument("--train-batch", type=int, default=16, help="frames per GPU of also_train416")
@@ -814,12 +818,12 @@ def main():
                          conv_mode=args.conv_mode, obj_bias=args.obj_bias, resident_fps=fps),
             workload="the headline step fed from the host: decoded %s uint8 frames in pinned host memory instead of a resident "
                      "fp32 batch (detect_yolo3.py:209-233, transforms.py:316-350)" % args.src_hw)
-        result["also_vid608"] = dict(
-            host_fed_leg(vy, dev, dist, rank, world, 608, args.vid_batch, 30, args.steps, args.warmup, hw(args.vid_src_hw),
+        result["also_vid%d" % args.vid_size] = dict(
+            host_fed_leg(vy, dev, dist, rank, world, args.vid_size, args.vid_batch, 30, args.steps, args.warmup, hw(args.vid_src_hw),
                          conv_mode=args.conv_mode),
-            workload="BASELINE.json configs[3]: ImageNet-VID-shape stream (30 classes), 608x608, one host clip batch of %d x %d "
+            workload="BASELINE.json configs[3]: ImageNet-VID-shape stream (30 classes), %dx%d, one host clip batch of %d x %d "
                      "frames (%s uint8) per step -> parallel.scatter_frames -> net -> parallel.gather_detections -> host"
-                     % (world, args.vid_batch, args.vid_src_hw))
+                     % (args.vid_size, args.vid_size, world, args.vid_batch, args.vid_src_hw))
         x = out = None
 
     if legs:

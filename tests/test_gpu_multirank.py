@@ -184,7 +184,7 @@ def test_bench_starts_its_own_ranks(extra):
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--share-gpu",
            "--size", "96", "--batch", "2", "--steps", "2", "--warmup", "1", "--cpu-frames", "0",
            "--train-size", "64", "--train-batch", "2", "--syncbn-size", "96", "--syncbn-batch", "2",
-           "--train-steps", "2", "--no-split-leg"] + extra   # (the split legs at 2 ranks: test_bench_under_torch_distributed_run)
+           "--train-steps", "2", "--no-split-leg", "--src-hw", "60x80", "--vid-src-hw", "48x64", "--vid-size", "96", "--vid-batch", "3"] + extra   # (the split legs at 2 ranks: test_bench_under_torch_distributed_run)
     p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
     assert p.returncode == 0, p.stderr.decode()[-2000:]
     lines = p.stdout.decode().splitlines()
@@ -199,6 +199,11 @@ def test_bench_starts_its_own_ranks(extra):
             assert k in t, k
         assert t["n_gpus"] == 2 and t["global_batch"] == 4 and t["size"] == 64 and t["frames_per_s"] > 0
         assert t["allreduce_bytes"] >= 61_000_000 * 4 and 0.0 <= t["allreduce_overlap_fraction"] <= 1.0
+        # the host-fed, pipelined legs: frames scattered, rows gathered (configs[3] shape: 30 classes) — every rank entered
+        hf, vid = r["also_hostfed96"], r["also_vid96"]
+        assert hf["n_gpus"] == 2 and hf["global_batch"] == 4 and hf["frames_per_s"] > 0 and hf["source_frames"].startswith("60x80")
+        assert vid["n_gpus"] == 2 and vid["classes"] == 30 and vid["global_batch"] == 6 and vid["frames_per_s"] > 0
+        assert "all-gather" in vid["pipeline"] and vid["copy_in_bytes"] == 3 * 48 * 64 * 3
         sb = r["also_syncbn608"]
         assert sb["n_gpus"] == 2 and sb["size"] == 96 and sb["frames_per_s"] > 0
         assert sb["batchnorm"].startswith("SyncBatchNorm(num_devices=2)")
@@ -219,14 +224,15 @@ def test_bench_under_torch_distributed_run():
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--share-gpu",
            "--size", "96", "--batch", "2", "--steps", "2", "--warmup", "1", "--cpu-frames", "0",
-           "--train-size", "64", "--train-batch", "2", "--syncbn-size", "96", "--syncbn-batch", "2", "--train-steps", "2"]
+           "--train-size", "64", "--train-batch", "2", "--syncbn-size", "96", "--syncbn-batch", "2", "--train-steps", "2",
+           "--src-hw", "60x80", "--vid-src-hw", "48x64", "--vid-size", "96", "--vid-batch", "2"]
     p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
     assert p.returncode == 0, p.stderr.decode()[-2000:]
     lines = p.stdout.decode().splitlines()
     assert len(lines) == 1 and lines[0].startswith("{"), p.stdout.decode()   # exactly the one line of the contract
     r = json.loads(lines[0])
     assert r["n_gpus"] == 2 and r["config"]["global_batch"] == 4 and r["value"] > 0 and r["scaling"] == "weak"
-    for leg in ("also_infer96_split", "also_train416", "also_train416_split", "also_syncbn608"):
+    for leg in ("also_infer96_split", "also_hostfed96", "also_vid96", "also_train416", "also_train416_split", "also_syncbn608"):
         assert leg in r and r[leg]["n_gpus"] == 2, leg
     assert r["also_train416_split"]["frames_per_s"] > 0 and r["also_infer96_split"]["frames_per_s"] > 0
 
@@ -235,7 +241,8 @@ def test_default_bench_line_has_the_training_leg_on_one_gpu():
     """N = 1, default mode (small shapes): also_train416 present with a measured `traffic` when rocprofv3 exists."""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--size", "96", "--batch", "2", "--steps", "2", "--warmup", "1",
-           "--cpu-frames", "1", "--train-size", "64", "--train-batch", "2", "--train-steps", "2"]
+           "--cpu-frames", "1", "--train-size", "64", "--train-batch", "2", "--train-steps", "2",
+           "--src-hw", "60x80", "--vid-src-hw", "48x64", "--vid-size", "96", "--vid-batch", "2"]
     p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1200)
     assert p.returncode == 0, p.stderr.decode()[-2000:]
     r = json.loads([l for l in p.stdout.decode().splitlines() if l.startswith("{")][0])
@@ -246,3 +253,6 @@ def test_default_bench_line_has_the_training_leg_on_one_gpu():
         assert r["roofline"]["traffic"] and t["traffic"] and t["traffic"] > 0, (r["roofline"].get("traffic_note"), t.get("traffic_note"))
     assert r["cpu_baseline"]["kind"] == "port" and r["cpu_baseline_torch"]["kind"] == "independent"
     assert r["cpu_baseline_torch"]["value"] > 0
+    hf = r["also_hostfed96"]
+    assert hf["n_gpus"] == 1 and hf["frames_per_s"] > 0 and hf["vs_resident"] > 0 and "exposed_ms_per_step" in hf
+    assert r["also_vid96"]["classes"] == 30 and "all-gather" not in r["also_vid96"]["pipeline"]

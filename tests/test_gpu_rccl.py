@@ -40,7 +40,8 @@ def test_bench_runs_its_training_legs_over_rccl_on_one_gpu():
     p = subprocess.run([sys.executable, os.path.join(os.path.dirname(HERE), "bench.py"), "--gpus", "1", "--backend", "nccl",
                         "--force-collectives", "--size", "96", "--batch", "2", "--steps", "2", "--warmup", "1",
                         "--train-size", "96", "--train-batch", "2", "--train-steps", "2", "--syncbn-size", "96",
-                        "--syncbn-batch", "2", "--cpu-frames", "0", "--no-pmc", "--no-latency", "--no-split-leg"],
+                        "--syncbn-batch", "2", "--cpu-frames", "0", "--no-pmc", "--no-latency", "--no-split-leg",
+                        "--src-hw", "60x80", "--vid-src-hw", "48x64", "--vid-size", "96", "--vid-batch", "2"],
                        env=env, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stderr[-3000:]
     r = json.loads(p.stdout.strip().splitlines()[-1])
@@ -49,3 +50,6 @@ def test_bench_runs_its_training_legs_over_rccl_on_one_gpu():
     assert leg["allreduce_alone_ms"] > 0 and leg["allreduce_bytes"] > 240e6
     assert "allreduce_exposed_ms" in leg and "allreduce_overlap_fraction" in leg
     assert r["also_syncbn608"]["batchnorm"].startswith("SyncBatchNorm(num_devices=1)")
+    # the result gather of the host-fed legs went through RCCL too (an all-gather over one rank)
+    assert "all-gather of the rows over nccl" in r["also_vid96"]["pipeline"] and r["also_vid96"]["frames_per_s"] > 0
+    assert "all-gather of the rows over nccl" in r["also_hostfed96"]["pipeline"]

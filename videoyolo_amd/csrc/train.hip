@@ -114,6 +114,14 @@ struct LabelLog {
 LabelLog g_labels;
 bool g_labels_done = false;
 
+// Measurement aid (tools/ab_bn_bounds.sh): VY_TRAIN_ABL skips BatchNorm launches of the training step to BOUND what
+// fusing them into the neighbouring conv launches could return — bit 1: bn_bwd_reduce (+ its finalize), 2: the forward
+// bn_apply, 4: bn_bwd_apply.  The step then computes garbage; nothing else reads this.
+static int train_abl() {
+  static const int v = getenv("VY_TRAIN_ABL") ? atoi(getenv("VY_TRAIN_ABL")) : 0;
+  return v;
+}
+
 constexpr int kBwdChunk = 64;  // pixels per partial-sum block of the bias-gradient reductions (and the scratch bound)
 
 VyTrain* get_train(vy_net* net) {
@@ -509,7 +517,7 @@ int forward_train(const TrainCtx& c, const float* x) {
       ap.r_cs = net->planes[cv.res_plane].C;
       ap.r_co = cv.res_co;
     }
-    HIP_TRY(vy_launch_bn_apply(ap, c.s));
+    if (!(train_abl() & 2)) HIP_TRY(vy_launch_bn_apply(ap, c.s));
   }
   return 0;
 }
@@ -753,7 +761,7 @@ int backward_train(const TrainCtx& c, const float* x) {
       bb.g_co = cv.out_co;
       bb.ups = cv.ups;
       bb.chunk = vy_bn_bwd_rows_per_chunk(B, zp.H, cv.cout);
-      HIP_TRY(vy_launch_bn_bwd_reduce(bb, c.s));
+      if (!(train_abl() & 1)) HIP_TRY(vy_launch_bn_bwd_reduce(bb, c.s));
       const bool exchange = sync_exchange(c.t) && is_sync_layer(cv);
       double count = (double)B * zp.H * zp.W;
       const double* use_sums = nullptr;
@@ -774,9 +782,9 @@ int backward_train(const TrainCtx& c, const float* x) {
       f.C = cv.cout;
       if (exchange)
         HIP_TRY(vy_launch_bn_bwd_finalize(f, c.s));
-      else
+      else if (!(train_abl() & 1))
         HIP_TRY(vy_launch_bn_bwd_reduce_finalize(c.partials(), vy_bn_bwd_chunks(bb), f, c.s));
-      HIP_TRY(vy_launch_bn_bwd_apply(bb, c.s));
+      if (!(train_abl() & 4)) HIP_TRY(vy_launch_bn_bwd_apply(bb, c.s));
       dzp = c.zplane(ci);
       dz_cs = zp.C;
       dzH = zp.H;

@@ -228,7 +228,7 @@ def gather_detections(ids, scores, bboxes, total=None):
     ``split_sizes(total, world)``, as ``scatter_frames`` cut them): no host-side size exchange, nothing waits for the
     GPU — the form a pipelined loop needs (videoyolo_amd/stream.py).  Without it the sizes are exchanged first."""
     import torch
-    if not is_initialized() or world_size() == 1:
+    if not collectives_active():   # one rank (unless VY_FORCE_COLLECTIVES sends it through the backend anyway)
         return ids, scores, bboxes
     dist = _dist()
     w, r = world_size(), rank()

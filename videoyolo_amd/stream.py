@@ -47,7 +47,7 @@ class HostFedDetector(object):
         self.b = self.sizes[self.rank]
         if self.b < 1:
             raise ValueError("rank %d gets no frame of a batch of %d" % (self.rank, self.global_batch))
-        self.gather = bool(gather) and self.world > 1
+        self.gather = bool(gather) and parallel.collectives_active()   # (> 1 rank, or one rank with VY_FORCE_COLLECTIVES)
         self.h, self.w = int(src_hw[0]), int(src_hw[1])
         self._mean, self._std = np.asarray(mean, np.float32), np.asarray(std, np.float32)
         self._lib = _lib.load()
