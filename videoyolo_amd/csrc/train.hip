@@ -116,7 +116,8 @@ bool g_labels_done = false;
 
 // Measurement aid (tools/ab_bn_bounds.sh): VY_TRAIN_ABL skips BatchNorm launches of the training step to BOUND what
 // fusing them into the neighbouring conv launches could return — bit 1: bn_bwd_reduce (+ its finalize), 2: the forward
-// bn_apply, 4: bn_bwd_apply.  The step then computes garbage; nothing else reads this.
+// bn_apply, 4: bn_bwd_apply; and, to see which stream of the backward pass holds the step, 8: no weight-gradient
+// kernels, 16: no data-gradient kernels.  The step then computes garbage; nothing else reads this.
 static int train_abl() {
   static const int v = getenv("VY_TRAIN_ABL") ? atoi(getenv("VY_TRAIN_ABL")) : 0;
   return v;
@@ -634,7 +635,9 @@ int launch_wgrad(const TrainCtx& c, size_t ci, const float* dzp, int dz_cs, int 
   if (!g_labels_done) g_labels.note("wgrad", cv.name, w.M, w.Cout, (double)cv.k * cv.k * cv.cin);
   // conv mode VY_CONV_SPLIT_BF16X3_TRAIN: the split-fp32 weight-gradient kernel where it has the tile (Cout % 128 == 0)
   static const int wgrad_split = getenv("VY_SPLIT_WGRAD") ? atoi(getenv("VY_SPLIT_WGRAD")) : 1;
-  if (wgrad_split && net->conv_mode == VY_CONV_SPLIT_BF16X3_TRAIN && vy_wgrad_split_supported(w)) {
+  if (train_abl() & 8) {
+    // (bound measurement: no weight-gradient kernel at all)
+  } else if (wgrad_split && net->conv_mode == VY_CONV_SPLIT_BF16X3_TRAIN && vy_wgrad_split_supported(w)) {
     HIP_TRY(vy_launch_wgrad_split(w, ws));
   } else {
     HIP_TRY(vy_launch_wgrad(w, ws));
@@ -837,6 +840,7 @@ int backward_train(const TrainCtx& c, const float* x) {
     const BwdDgrad dg = make_dgrad(c, cv, dzp, dz_cs, dzH, dzW, addend, add_cs, add_co);
     for (int k = 0; k < dg.n; ++k) {
       if (!g_labels_done) g_labels.note("dgrad", cv.name, dg.a[k].M, dg.a[k].N, (double)dg.a[k].ntaps * dg.a[k].Kc);
+      if (train_abl() & 16) continue;  // (bound measurement: no data-gradient kernel)
       if (int rc = launch_conv(dg.a[k], c.s)) return rc;
     }
     if (cov == 0) touched[cv.in_plane].push_back({lo, hi});
