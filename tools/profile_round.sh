@@ -10,10 +10,10 @@ O=$R/gpurun_out
 cd /tmp
 python3 $R/bench.py > $O/${tag}_infer608_b64_bench.json 2> /dev/null
 python3 $R/bench.py --mode train > $O/${tag}_train416_b16_bench.json 2> /dev/null
-Q="--cpu-frames 0 --no-roofline --no-pmc --no-latency --no-train-legs --no-split-leg"
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/${tag}_p_inf -- python3 $R/bench.py --steps 5 --warmup 2 --cpu-frames 0 --no-pmc --no-latency --no-train-legs --no-split-leg > $O/${tag}_infer608_b64_bench_under_rocprof.json 2> /dev/null
+Q="--cpu-frames 0 --no-roofline --no-pmc --no-latency --no-train-legs --no-split-leg --no-host-legs"
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/${tag}_p_inf -- python3 $R/bench.py --steps 5 --warmup 2 --cpu-frames 0 --no-pmc --no-latency --no-train-legs --no-split-leg --no-host-legs > $O/${tag}_infer608_b64_bench_under_rocprof.json 2> /dev/null
 # the opt-in split-fp32 conv mode as the profiled step (its own kernel stats, MFMA-busy counters and layer table)
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/${tag}_p_spl -- python3 $R/bench.py --conv-mode split_bf16x3 --steps 5 --warmup 2 --cpu-frames 0 --no-pmc --no-latency --no-train-legs > $O/${tag}_infer608_b64_split_bench_under_rocprof.json 2> /dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/${tag}_p_spl -- python3 $R/bench.py --conv-mode split_bf16x3 --steps 5 --warmup 2 --cpu-frames 0 --no-pmc --no-latency --no-train-legs --no-host-legs > $O/${tag}_infer608_b64_split_bench_under_rocprof.json 2> /dev/null
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${tag}_p_trn -- python3 $R/bench.py --mode train --steps 10 --warmup 3 --no-pmc > $O/${tag}_train416_b16_bench_under_rocprof.json 2> /dev/null
 MF="SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS GRBM_GUI_ACTIVE"
 for m in inf trn spl; do

@@ -103,3 +103,107 @@ for m, (wname, cmd) in WORK.items():
         print("%-60s mfma busy %.3f  cu busy %.3f" % (k[:60], v["mfma_busy_frac"], v["cu_busy_frac"]))
     for k, v in hbm["kernels"].items():
         print("%-60s HBM %.1f MB/launch x %d" % (k[:60], v["hbm_MB_per_launch"], v["dispatches"]))
+
+
+# ---- profiles/<out>_summary.md: every number table of the round, generated from the committed JSON / CSV files above
+# (DESIGN.md quotes this file; nothing in it is typed by hand) -----------------------------------------------------------
+def _load(name):
+    f = os.path.join(P, name)
+    if not os.path.exists(f):
+        return None
+    raw = open(f).read().strip()
+    try:
+        return json.loads(raw)
+    except ValueError:
+        pass
+    txt = raw.splitlines()   # (a bench output with library chatter before its one line)
+    for line in reversed(txt):
+        if line.startswith("{"):
+            return json.loads(line)
+    return None
+
+
+def _f(v, fmt="%.1f"):
+    return "—" if v is None else fmt % v
+
+
+def write_summary():
+    b = _load("%s_infer608_b64_bench.json" % out)
+    t = _load("%s_train416_b16_bench.json" % out)
+    if not b:
+        return
+    L = ["# Round summary `%s` (generated by tools/summarize_profiles.py from the files in this directory)" % out, "",
+         "All numbers: ONE MI355X, one box (boxes of the pool differ by a few percent; ratios are same-run).", "",
+         "## Inference (`%s_infer608_b64_bench.json`: `python bench.py`)" % out, "",
+         "| leg | frames/s | ms/step | note |", "|---|---|---|---|"]
+    r = b.get("roofline", {})
+    L.append("| **headline**: 608², batch 64, 20 classes, exact fp32, frames resident | **%s** | %s | dominant kernel `%s`: %s TF = **%s** of the fp32 MFMA roof (%s launches, %s ms each); all conv launches %s; whole step %s TF; traffic %s GB per dominant launch (%s× algorithmic) |"
+             % (_f(b["value"]), _f(b["ms_per_step"], "%.2f"), r.get("kernel"), _f(r.get("achieved")), _f(r.get("frac"), "%.3f"),
+                r.get("launches_per_step"), _f(r.get("avg_launch_ms"), "%.3f"), _f(r.get("frac_all_conv"), "%.3f"),
+                _f(r.get("whole_step_tflops")), _f((r.get("traffic") or 0) / 1e9, "%.2f") if r.get("traffic") else "—",
+                _f((r.get("traffic_detail") or {}).get("over_algorithmic"), "%.2f")))
+    a4 = b.get("also_416")
+    if a4:
+        L.append("| 416², batch 64 (`also_416`) | %s | %s | %s of the roof |" % (_f(a4["frames_per_s"]), _f(a4["ms_per_step"], "%.2f"), _f(a4.get("frac_of_fp32_mfma_peak"), "%.3f")))
+    lb = b.get("latency_batch1")
+    if lb:
+        L.append("| one frame 608² (`latency_batch1`) | %s | %s | eager; HIP graph %s ms; %s of the roof |"
+                 % (_f(1e3 / lb["eager_ms"]), _f(lb["eager_ms"], "%.3f"), _f(lb["hip_graph_ms"], "%.3f"), _f(lb.get("frac_of_fp32_mfma_peak"), "%.2f")))
+    for key, label in (("also_hostfed608", "host-fed, pipelined (`also_hostfed608`)"), ("also_vid608", "configs[3]: 30 classes, host clip batch → scatter → net → gather (`also_vid608`)")):
+        h = b.get(key)
+        if h:
+            L.append("| %s | %s | %s | source %s; copy-in alone %s ms (%s GB/s), copy-out %s ms%s |"
+                     % (label, _f(h["frames_per_s"]), _f(h["ms_per_step"], "%.2f"), h["source_frames"], _f(h["copy_in_alone_ms"], "%.2f"),
+                        _f(h["copy_in_GBps"]), _f(h["copy_out_alone_ms"], "%.3f"),
+                        "; %s of the resident rate, %s ms per step exposed" % (_f(h["vs_resident"], "%.3f"), _f(h["exposed_ms_per_step"], "%.2f")) if "vs_resident" in h else ""))
+    s = b.get("also_infer608_split")
+    if s:
+        sr = s.get("roofline", {})
+        L.append("| opt-in conv mode `split_bf16x3` (`also_infer608_split`; NOT the parity path) | %s | %s | %s× the exact step; split + Winograd launches %s TF-equivalent = %s of the bf16 roof ÷ 6 (%s of the fp32 roof), bf16 issued %s TF; Winograd %s launches %s ms; traffic %s GB per launch (%s×); one frame %s ms |"
+                 % (_f(s["frames_per_s"]), _f(s["ms_per_step"], "%.2f"), _f(s["speedup_over_exact"], "%.3f"), _f(sr.get("achieved_fp32_equivalent")),
+                    _f(sr.get("frac_vs_bf16_peak_over_6_419"), "%.3f"), _f(sr.get("frac_vs_fp32_mfma_peak_157"), "%.2f"), _f(sr.get("bf16_mfma_tflops"), "%.0f"),
+                    sr.get("winograd_launches"), _f(sr.get("winograd_ms"), "%.2f"), _f((sr.get("traffic") or 0) / 1e9, "%.2f") if sr.get("traffic") else "—",
+                    _f((sr.get("traffic_detail") or {}).get("over_algorithmic"), "%.2f"), _f((s.get("latency_batch1") or {}).get("eager_ms"), "%.3f")))
+    for key in ("cpu_baseline", "cpu_baseline_torch"):
+        c = b.get(key)
+        if c and c.get("value"):
+            L.append("| `%s` (%s, %d host threads; NOT MXNet) | %s | — | %s |" % (key, c["kind"], c["cores"], _f(c["value"], "%.2f"), c["sample"][:110]))
+    L += ["", "## Training (`also_train416*` of the same line; `%s_train416_b16_bench.json`: `python bench.py --mode train`)" % out, "",
+          "| leg | frames/s | ms/step | of the fp32 roof | forward / backward ms | traffic GB/step |", "|---|---|---|---|---|---|"]
+    for key, label in (("also_train416", "configs[2]: 416², 16 per GPU, exact"), ("also_train416_split", "the same, conv mode `split_bf16x3_train`"), ("also_syncbn608", "configs[4] (N > 1 only)")):
+        g = b.get(key)
+        if g:
+            L.append("| %s (`%s`) | %s | %s | %s | %s / %s | %s |" % (label, key, _f(g["frames_per_s"]), _f(g["ms_per_step"], "%.2f"), _f(g.get("frac"), "%.3f"),
+                                                                  _f(g.get("forward_ms"), "%.2f"), _f(g.get("backward_ms"), "%.2f"),
+                                                                  _f(g["traffic"] / 1e9) if g.get("traffic") else "—"))
+    if t:
+        L.append("| `--mode train` as the headline | %s | %s | %s | %s / %s | %s |"
+                 % (_f(t["value"]), _f(t["ms_per_step"], "%.2f"), _f((t.get("roofline") or {}).get("frac"), "%.3f"),
+                    _f((t.get("step_split") or {}).get("forward_ms"), "%.2f"), _f((t.get("step_split") or {}).get("backward_ms"), "%.2f"),
+                    _f((t.get("roofline") or {}).get("traffic", 0) / 1e9) if (t.get("roofline") or {}).get("traffic") else "—"))
+    # rocprofv3 kernel stats: the ten largest kernels of the profiled inference command
+    ks = os.path.join(P, "%s_infer608_b64_kernel_stats.csv" % out)
+    if os.path.exists(ks):
+        rows = sorted(csv.DictReader(open(ks)), key=lambda q: -float(q["TotalDurationNs"]))
+        tot = sum(float(q["TotalDurationNs"]) for q in rows)
+        L += ["", "## rocprofv3 --kernel-trace --stats of the inference command (`%s_infer608_b64_kernel_stats.csv`)" % out, "",
+              "| kernel | calls | avg µs | share |", "|---|---|---|---|"]
+        for q in rows[:8]:
+            L.append("| `%s` | %s | %.1f | %.1f %% |" % (short(q["Name"])[:80], q["Calls"], float(q["AverageNs"]) / 1e3, 100 * float(q["TotalDurationNs"]) / tot))
+    for wname, title in (("infer608_b64", "exact inference"), ("infer608_b64_split", "split inference"), ("train416_b16", "training")):
+        mf, hb = _load("%s_%s_pmc_mfma.json" % (out, wname)), _load("%s_%s_pmc_hbm.json" % (out, wname))
+        if not mf or not hb:
+            continue
+        L += ["", "## Counters, %s (`%s_%s_pmc_mfma.json`, `_pmc_hbm.json`; separate passes)" % (title, out, wname), "",
+              "| kernel | launches | MFMA-busy | CU-busy | VALU : MFMA instructions | HBM MB per launch |", "|---|---|---|---|---|---|"]
+        ks_ = sorted(mf["kernels"].items(), key=lambda kv: -kv[1]["dispatches"] * kv[1]["mfma_busy_frac"])[:8]
+        for k, v in ks_:
+            ins = v["insts_per_launch"]
+            ratio = ins.get("valu", 0) / ins["mfma"] if ins.get("mfma") else None
+            h = hb["kernels"].get(k, {})
+            L.append("| `%s` | %d | %.3f | %.3f | %s | %s |" % (k[:70], v["dispatches"], v["mfma_busy_frac"], v["cu_busy_frac"], _f(ratio, "%.2f"), _f(h.get("hbm_MB_per_launch"))))
+    open(os.path.join(P, "%s_summary.md" % out), "w").write("\n".join(L) + "\n")
+    print("wrote profiles/%s_summary.md" % out)
+
+
+write_summary()
