@@ -749,7 +749,7 @@ def main():
                 "kernel_share_of_step_time": sp_ms / tot_ms,
                 "by_kernel_ms": {k: round(a[1], 4) for k, a in sagg.items()}, "traffic": None}
             if split_traffic:
-                keys = [k for k in split_traffic if k.startswith("void conv_split_kernel") or k.startswith("conv_wino_kernel")]
+                keys = [k for k in split_traffic if isinstance(split_traffic[k], dict) and ("conv_split_kernel" in k or "conv_wino_kernel" in k)]
                 n_l = sum(split_traffic[k]["launches"] for k in keys)
                 if n_l:
                     hb = sum(split_traffic[k]["hbm_bytes"] * split_traffic[k]["launches"] for k in keys) / n_l

@@ -23,6 +23,17 @@ def test_detect_example():
     assert "3 frames" in out and "prediction lines" in out and "mAP" in out
 
 
+def test_detect_example_pipelined_equals_synchronous_and_two_ranks():
+    """examples/detect.py is the pipelined host-fed loop (videoyolo_amd/stream.py); --sync is the reference's shape (transform,
+    net(x), .cpu(), one after the other); --gpus 2 scatters every clip batch over two ranks (sharing the test box's GPU over
+    gloo) and gathers the rows to rank 0.  All three print the same prediction lines and the same mAP."""
+    a = _run(["examples/detect.py", "--size", "416", "--batch", "4", "--frames", "10"])
+    b = _run(["examples/detect.py", "--size", "416", "--batch", "4", "--frames", "10", "--sync"])
+    c = _run(["examples/detect.py", "--size", "416", "--batch", "4", "--frames", "10", "--gpus", "2", "--backend", "gloo", "--share-gpu"])
+    pick = lambda o: [l for l in o.splitlines() if "prediction lines" in l or "mAP" in l]  # noqa: E731
+    assert len(pick(a)) == 2 and pick(a) == pick(b) == pick(c)
+
+
 def test_detect_example_in_the_split_conv_mode():
     exact = _run(["examples/detect.py", "--size", "416", "--batch", "2", "--frames", "3"])
     split = _run(["examples/detect.py", "--size", "416", "--batch", "2", "--frames", "3", "--conv-mode", "split_bf16x3"])
