@@ -382,8 +382,8 @@ def host_fed_leg(vy, dev, dist, rank, world, size, batch, classes, steps, warmup
     rng = np.random.default_rng(77)
     # the same clip batches on every rank (a shared decoder / file; a rank touches only its slice); two distinct ones at
     # N = 1, one at N > 1 (every rank process holds the WHOLE clip batch in host memory: 1.4 GB of 720p frames at N = 8)
-    clips = [rng.integers(0, 256, (gb, h, w, 3), dtype=np.uint8) for _ in range(2 if world == 1 else 1)]
-    clips = clips * 2
+    clips = [torch.from_numpy(rng.integers(0, 256, (gb, h, w, 3), dtype=np.uint8)).pin_memory() for _ in range(2 if world == 1 else 1)]
+    clips = clips * 2   # pinned host memory: what a decoder's output buffers are (copied in without a staging copy)
     det = stream.HostFedDetector(net, gb, (h, w), size, depth=2, gather=True)
     kept = 0
     for i, out in enumerate(det.run(clips[i & 1] for i in range(warmup))):
@@ -415,7 +415,7 @@ def host_fed_leg(vy, dev, dist, rank, world, size, batch, classes, steps, warmup
            "copy_in_alone_ms": sorted(cin)[len(cin) // 2], "copy_in_bytes": int(det.pin_in[0].numel()),
            "copy_in_GBps": det.pin_in[0].numel() / (sorted(cin)[len(cin) // 2] * 1e-3) / 1e9,
            "copy_out_alone_ms": sorted(cout)[len(cout) // 2], "copy_out_bytes": int(det.pin_out[0].numel() * 4),
-           "pipeline": "pinned host uint8 -> H2D (copy stream) -> resize + to_tensor + normalise -> net -> %s-> D2H (copy stream); "
+           "pipeline": "uint8 frames in pinned host memory -> H2D (copy stream) -> resize + to_tensor + normalise -> net -> %s-> D2H (copy stream); "
                        "2 slots" % ("all-gather of the rows over %s " % dist.get_backend() if det.gather else "")}
     if resident_fps:
         # what feeding from the host costs per step beyond the resident step (pre-processing kernel + whatever of the copies

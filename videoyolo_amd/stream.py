@@ -64,11 +64,13 @@ class HostFedDetector(object):
             self.e_in, self.e_pre, self.e_cmp, self.e_out = ev(), ev(), ev(), ev()
         self._n = 0
         self._busy = [False] * depth
+        self._src = [None] * depth
 
     # -- one batch -------------------------------------------------------------------------------------------------
     def submit(self, clip_batch):
-        """Enqueue one clip batch: (global_batch, h, w, 3) uint8 on the host (numpy, or a torch CPU tensor).  Returns the
-        slot to pass to ``result``.  Never waits for the GPU unless every slot is still in flight."""
+        """Enqueue one clip batch: (global_batch, h, w, 3) uint8 on the host (numpy, or a torch CPU tensor — pinned: copied
+        in directly; pageable: through this slot's pinned staging buffer).  Returns the slot to pass to ``result``.  Never
+        waits for the GPU unless every slot is still in flight."""
         torch = _torch()
         k = self._n % self.depth
         if self._busy[k]:
@@ -81,14 +83,21 @@ class HostFedDetector(object):
         if src.dtype != torch.uint8:
             raise TypeError("frames must be uint8 (decoded images), got %s" % src.dtype)
         cur = torch.cuda.current_stream(self.dev)
-        if self._n >= self.depth:
-            self.e_in[k].synchronize()            # the copy-in of this slot's previous batch has left the pinned buffer
-        self.pin_in[k].copy_(src)                 # (a decoder would write here directly)
+        if src.is_pinned() and src.is_contiguous():
+            # the frames already lie in pinned host memory (a decoder's output buffer): copied in straight from there.  The
+            # caller must leave them alone until this batch's result has been collected
+            staged = src
+        else:
+            if self._n >= self.depth:
+                self.e_in[k].synchronize()        # the copy-in of this slot's previous batch has left the staging buffer
+            self.pin_in[k].copy_(src)             # pageable memory: one host copy into this slot's pinned staging buffer
+            staged = self.pin_in[k]
+        self._src[k] = staged                     # (kept alive until the slot is reused)
         with torch.cuda.device(self.dev):
             with torch.cuda.stream(self.s_in):
                 if self._n >= self.depth:
                     self.s_in.wait_event(self.e_pre[k])   # the pre-processing that read dev_in[k] has run
-                self.dev_in[k].copy_(self.pin_in[k], non_blocking=True)
+                self.dev_in[k].copy_(staged, non_blocking=True)
                 self.e_in[k].record(self.s_in)
             cur.wait_event(self.e_in[k])
             if self._n >= self.depth:
