@@ -382,7 +382,9 @@ def host_fed_leg(vy, dev, dist, rank, world, size, batch, classes, steps, warmup
     rng = np.random.default_rng(77)
     # the same clip batches on every rank (a shared decoder / file; a rank touches only its slice); two distinct ones at
     # N = 1, one at N > 1 (every rank process holds the WHOLE clip batch in host memory: 1.4 GB of 720p frames at N = 8)
-    clips = [torch.from_numpy(rng.integers(0, 256, (gb, h, w, 3), dtype=np.uint8)).pin_memory() for _ in range(2 if world == 1 else 1)]
+    # (random bytes are drawn for ONE rank's slice and repeated for the others: 1.4 GB of them per clip would take seconds)
+    clips = [torch.from_numpy(np.tile(rng.integers(0, 256, (batch, h, w, 3), dtype=np.uint8), (world, 1, 1, 1))).pin_memory()
+             for _ in range(2 if world == 1 else 1)]
     clips = clips * 2   # pinned host memory: what a decoder's output buffers are (copied in without a staging copy)
     det = stream.HostFedDetector(net, gb, (h, w), size, depth=2, gather=True)
     kept = 0

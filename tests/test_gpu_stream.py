@@ -68,6 +68,25 @@ def test_pipelined_stream_equals_the_synchronous_path(src_hw, size, batch, n):
         det.submit(clips[0].astype(np.float32))
 
 
+def test_full_size_stream_of_configs3():
+    """BASELINE configs[3]'s shape through the pipelined loop: 30 classes, 608 x 608, clip batches of 32 frames of 360 x 640
+    uint8 video (bicubic enlargement on the GPU), four batches over two slots — every batch bit-equal to the synchronous
+    path, results in order."""
+    from videoyolo_amd import stream
+    rng = np.random.default_rng(9)
+    pool = [rng.integers(0, 256, (32, 360, 640, 3), dtype=np.uint8) for _ in range(2)]
+    clips = [pool[0], pool[1], pool[1][::-1].copy(), pool[0]]
+    net = _net(30)
+    want = [_sync_path(net, c, 608) for c in clips[:3]]
+    det = stream.HostFedDetector(net, 32, (360, 640), 608, depth=2)
+    got = [[np.array(a) for a in out] for out in det.run(iter(clips))]
+    for i, g in enumerate(got):
+        w = want[i] if i < 3 else want[0]
+        assert all(np.array_equal(a, b) for a, b in zip(g, w)), "batch %d" % i
+    assert np.array_equal(got[2][0], want[1][0][::-1])      # frames are independent: the reversed clip gives the reversed rows
+    assert (want[0][0] >= 0).sum() > 32
+
+
 @pytest.mark.parametrize("global_batch", [5, 4])
 def test_two_ranks_scatter_and_gather_equal_one_rank(global_batch, tmp_path):
     from videoyolo_amd import launch

@@ -5,9 +5,9 @@
 and the kernels of a batch never overlap, and neither do two batches.  Here one process drives one GPU, and a batch
 goes through three HIP streams:
 
-    host (pinned uint8 frames)  --copy-in stream-->  device uint8
-    device uint8  --compute stream-->  resize + to_tensor + normalise (csrc/preproc.hip, one kernel)  ->  net(x)
-                                       [-> all-gather of the (B, R, 6) rows over RCCL when there are several ranks]
+    host (pinned uint8 frames)  --copy-in stream-->  device uint8 -> resize + to_tensor + normalise (csrc/preproc.hip, one
+                                                     kernel, on the copy stream too: it runs beside the previous batch's convs)
+    device fp32 batch  --compute stream-->  net(x)  [-> all-gather of the (B, R, 6) rows over RCCL when there are several ranks]
     device rows   --copy-out stream-->  host (pinned fp32 rows)
 
 with ``depth`` buffer slots (2: double-buffered), HIP events between the streams and NO host synchronisation except when
@@ -96,17 +96,21 @@ class HostFedDetector(object):
         with torch.cuda.device(self.dev):
             with torch.cuda.stream(self.s_in):
                 if self._n >= self.depth:
-                    self.s_in.wait_event(self.e_pre[k])   # the pre-processing that read dev_in[k] has run
+                    # slot k's previous batch: its pre-processing has read dev_in[k] (same stream: ordered) and its
+                    # forward has read x[k] (the compute stream's e_cmp)
+                    self.s_in.wait_event(self.e_cmp[k])
                 self.dev_in[k].copy_(staged, non_blocking=True)
                 self.e_in[k].record(self.s_in)
-            cur.wait_event(self.e_in[k])
+                # resize + to_tensor + normalise ON THE COPY STREAM: a bandwidth-bound kernel that runs beside the
+                # previous batch's matrix-bound convs instead of in front of this batch's
+                _lib.check(self._lib.vy_preprocess_resize_frames(
+                    ctypes.c_void_p(self.dev_in[k].data_ptr()), self.h, self.w, ctypes.c_void_p(self.x[k].data_ptr()), self.b,
+                    self.size, self.size, self._mean.ctypes.data_as(ctypes.c_void_p), self._std.ctypes.data_as(ctypes.c_void_p),
+                    ctypes.c_void_p(self.s_in.cuda_stream)))
+                self.e_pre[k].record(self.s_in)
+            cur.wait_event(self.e_pre[k])
             if self._n >= self.depth:
                 cur.wait_event(self.e_out[k])             # dev_out[k] has been copied out
-            _lib.check(self._lib.vy_preprocess_resize_frames(
-                ctypes.c_void_p(self.dev_in[k].data_ptr()), self.h, self.w, ctypes.c_void_p(self.x[k].data_ptr()), self.b,
-                self.size, self.size, self._mean.ctypes.data_as(ctypes.c_void_p), self._std.ctypes.data_as(ctypes.c_void_p),
-                ctypes.c_void_p(cur.cuda_stream)))
-            self.e_pre[k].record(cur)
             ids, scores, bboxes = self.net(self.x[k])
             if self.gather:
                 g_ids, g_scores, g_bboxes = parallel.gather_detections(ids, scores, bboxes, total=self.global_batch)
