@@ -248,3 +248,22 @@ def test_training_call_structure(golden, key, ncls):
     # train-mode, not recording: (box_preds, [anchors] x 3, [offsets] x 3, [fake featmaps] x 3, centers, scales, objness, classes)
     assert t["train_mode_tuple"] == ["pred[-1:0:2]", ["const:anchors"] * 3, ["const:offsets"] * 3, ["zeros"] * 3,
                                      "pred[-1:0:2]", "pred[-1:2:4]", "pred[-1:4:5]", "pred[-1:5:None]"]
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/models/definitions"), reason="build container only: needs /root/reference")
+def test_fixture_is_what_the_recorder_writes_today(golden, tmp_path):
+    """Where the reference tree is present (the build container, never the GPU box) the recorder is re-run in a child process and
+    must reproduce the committed fixture exactly: the fixture cannot drift from its generating script."""
+    import subprocess
+    import sys
+    script = os.path.join(HERE, "golden", "make_graph_structure.py")
+    # the script writes next to itself: run a copy that writes into tmp_path
+    src = open(script).read().replace('OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "graph_structure.json")',
+                                      "OUT = %r" % str(tmp_path / "g.json"))
+    copy = tmp_path / "make_graph_structure.py"
+    copy.write_text(src)
+    p = subprocess.run([sys.executable, str(copy)], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    with open(tmp_path / "g.json") as f:
+        fresh = json.load(f)
+    assert fresh == golden
