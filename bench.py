@@ -802,6 +802,8 @@ def main():
             tdt = torch_cpu_baseline(params, x[:nt].cpu().numpy(), args.classes)
             result["cpu_baseline_torch"] = {
                 "value": nt / tdt, "unit": "frames/s", "cores": int(torch.get_num_threads()),
+                "host": {"cpu_count": os.cpu_count(), "affinity": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None,
+                         "fp32_tflops": nt / tdt * FWD_GFLOP_PER_FRAME.get((args.size, args.classes), 0.0) / 1e3},
                 "kind": "independent", "sample": "%d frames of the same batch, as ONE batch, through torch-CPU conv2d / batch_norm / "
                 "leaky_relu of the same 75-conv graph (no decode / NMS); an independent CPU datapoint, NOT MXNet and not the checker"
                 % nt}
