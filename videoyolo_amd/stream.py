@@ -43,7 +43,6 @@ class HostFedDetector(object):
         self.world, self.rank = parallel.world_size(), parallel.rank()
         self.global_batch = int(global_batch)
         self.sizes = parallel.split_sizes(self.global_batch, self.world)
-        self.lo = sum(self.sizes[:self.rank])
         self.b = self.sizes[self.rank]
         if self.b < 1:
             raise ValueError("rank %d gets no frame of a batch of %d" % (self.rank, self.global_batch))
