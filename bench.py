@@ -521,7 +521,7 @@ def main():
     ap.add_argument("--vid-src-hw", default="360x640", help="also_vid608: size of the uint8 source frames (HxW)")
     ap.add_argument("--vid-batch", type=int, default=64, help="also_vid608: frames per GPU and clip batch")
     ap.add_argument("--vid-size", type=int, default=608, help="also_vid608: network input size (tests use small ones)")
-    ap.add_argument("--train-steps", type=int, default=10, help="timed steps of each training leg")
+    ap.add_argument("--train-steps", type=int, default=20, help="timed steps of each training leg (20: a 0.6 s window; 10 was short enough for one host hiccup to cost 10 %)")
     ap.add_argument("--train-size", type=int, default=416)
     ap.add_argument("--train-batch", type=int, default=16, help="frames per GPU of also_train416")
     ap.add_argument("--syncbn-size", type=int, default=608)
