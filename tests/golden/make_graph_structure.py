@@ -154,6 +154,21 @@ class Param:
     def __init__(self, name, value=None, **kw):
         self.name, self.value, self.grad_req, self.kw = name, value, "write", kw
         self.wd_mult = self.lr_mult = 1.0
+        self.shape = None      # set by the layer once its input channels are known
+        self._data = None      # reset_class recording only: a numpy array; NaN = "freshly initialised, never written"
+
+    def list_ctx(self):
+        return ["cpu(0)"]
+
+    def data(self, ctx=None):
+        import numpy as np
+        if self._data is None:
+            self._data = np.full(self.shape, np.nan, np.float64)
+        return self._data
+
+    def set_data(self, value):
+        import numpy as np
+        self._data = np.array(value, np.float64)
 
 
 class ParamDict(collections.OrderedDict):
@@ -273,9 +288,18 @@ class Conv2D(HybridBlock):
         self.weight = self.params.get("weight")
         if use_bias:
             self.bias = self.params.get("bias")
+        if in_channels:
+            self._set_shapes(int(in_channels))
+
+    def _set_shapes(self, cin):
+        self.weight.shape = (self.spec["cout"], cin) + tuple(self.spec["kernel"])
+        if self.spec["use_bias"]:
+            self.bias.shape = (self.spec["cout"],)
 
     def forward(self, x):
-        rec = dict(self.spec, cin=x.c, name=self._path, exec_index=len(TRACE.convs))
+        if self.weight.shape is None and x.c is not None:
+            self._set_shapes(x.c)                       # gluon's deferred shape inference, at the first forward
+        rec = dict(self.spec, cin=x.c, name=getattr(self, "_path", "?"), exec_index=len(TRACE.convs))
         TRACE.convs.append(rec)
         return T(self.spec["cout"], self._path)
 
@@ -508,6 +532,74 @@ def record(num_class, sync):
     }
 
 
+def record_reset_class():
+    """The reference's own reset_class (yolo3.py:1230-1302 + YOLOOutputV3.reset_class :76-129) EXECUTED on marker values:
+    which row of the new prediction conv holds which old row (or stays freshly initialised), for the forms of
+    `reuse_weights` its docstring lists.  Pure data movement: no operator arithmetic is involved."""
+    import warnings
+    import numpy as np
+    from models.definitions.yolo.wrappers import yolo3_darknet53
+    voc = ["aeroplane", "bicycle", "bird", "boat", "bottle", "bus", "car", "cat", "chair", "cow", "diningtable", "dog", "horse",
+           "motorbike", "person", "pottedplant", "sheep", "sofa", "train", "tvmonitor"]
+
+    def fresh_net():
+        net = yolo3_darknet53(list(voc), pretrained_base=False, k=1)
+        name_paths(net)
+        TRACE.reset()
+        net(T(3, "input"))                              # every Conv2D learns its input channels
+        for i, o in enumerate(net.yolo_outputs):
+            w, b = o.prediction.weight, o.prediction.bias
+            rows = np.arange(w.shape[0], dtype=np.float64)
+            w.set_data(np.broadcast_to((1000.0 * (i + 1) + rows).reshape(-1, 1, 1, 1), w.shape))   # marker = 1000 (head + 1) + row
+            b.set_data(1000.0 * (i + 1) + rows + 0.5)
+        return net
+
+    def rows_of(net):
+        out = []
+        for i, o in enumerate(net.yolo_outputs):
+            w, b = o.prediction.weight.data(), o.prediction.bias.data()
+            assert w.shape[0] == 3 * (5 + len(net.classes)) and b.shape == (w.shape[0],)
+            src_w = [(-1 if np.isnan(v) else int(round(v - 1000.0 * (i + 1)))) for v in w[:, 0, 0, 0]]
+            src_b = [(-1 if np.isnan(v) else int(round(v - 0.5 - 1000.0 * (i + 1)))) for v in b]
+            assert src_w == src_b and all(np.isnan(r).all() or (r == r.flat[0]).all() for r in w.reshape(w.shape[0], -1))
+            out.append(src_w)
+        return out
+
+    cases = [
+        ("names", ["person", "car", "dog"], {"person": "person", "car": "car", "dog": "dog"}),
+        ("indices", ["person"], {0: 14}),
+        ("mixed", ["cat", "person", "zebra"], {"person": 14, 0: "cat"}),
+        ("list", ["bird", "cat", "zebra"], ["cat", "bird", "unicorn"]),
+        ("none", ["a", "b"], None),
+        ("empty_dict", ["a", "b"], {}),
+        ("more_classes", voc + ["zebra", "unicorn"], voc),
+        ("same_classes_permuted", voc[::-1], voc),
+    ]
+    out = {"marker": "new prediction row r of head i holds old row src[i][r] (weights and bias alike), -1 = freshly initialised",
+           "old_classes": voc, "cases": []}
+    for label, classes, reuse in cases:
+        net = fresh_net()
+        with warnings.catch_warnings(record=True) as wl:
+            warnings.simplefilter("always")
+            net.reset_class(list(classes), reuse_weights=(dict(reuse) if isinstance(reuse, dict) else (list(reuse) if reuse is not None else None)))
+        out["cases"].append({"label": label, "classes": list(classes),
+                             "reuse_weights": ([[k, v] for k, v in reuse.items()] if isinstance(reuse, dict) else reuse),
+                             "src_rows": rows_of(net), "warnings": [str(w.message) for w in wl],
+                             "classes_after": list(net.classes),
+                             "merger_num_class": net._target_generator._num_class})
+    errors = []
+    for classes, reuse in ((["person"], {"person": "unicorn"}), (["person"], {"unicorn": "person"}), (["person"], {0: 20}),
+                           (["person"], {1: 14}), (["person"], {0: -1})):
+        net = fresh_net()
+        try:
+            net.reset_class(list(classes), reuse_weights=dict(reuse))
+            errors.append({"classes": classes, "reuse_weights": [[k, v] for k, v in reuse.items()], "raises": None})
+        except ValueError as e:
+            errors.append({"classes": classes, "reuse_weights": [[k, v] for k, v in reuse.items()], "raises": "ValueError", "message": str(e)})
+    out["errors"] = errors
+    return out
+
+
 def main():
     install()
     doc = {
@@ -520,6 +612,7 @@ def main():
         "voc20": record(20, sync=False),
         "vid30": record(30, sync=False),
         "voc20_syncbn8": record(20, sync=True),
+        "reset_class": record_reset_class(),
     }
     with open(OUT, "w") as f:
         json.dump(doc, f, indent=1, sort_keys=False)

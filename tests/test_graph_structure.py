@@ -267,3 +267,64 @@ def test_fixture_is_what_the_recorder_writes_today(golden, tmp_path):
     with open(tmp_path / "g.json") as f:
         fresh = json.load(f)
     assert fresh == golden
+
+
+def _marked_net(classes):
+    """a host-side net whose prediction convs hold marker values: row r of head i = 1000 (i + 1) + r (bias: + 0.5)"""
+    import videoyolo_amd as vy
+    net = vy.yolo3_darknet53(list(classes), pretrained_base=False)
+    net.initialize(init="synthetic", seed=3)
+    for i in range(3):
+        w = net.collect_params()["yolo_outputs.%d.prediction.weight" % i]
+        b = net.collect_params()["yolo_outputs.%d.prediction.bias" % i]
+        rows = np.arange(w.shape[0], dtype=np.float32)
+        w.set_data(np.broadcast_to((1000.0 * (i + 1) + rows).reshape(-1, 1, 1, 1), w.shape).astype(np.float32))
+        b.set_data((1000.0 * (i + 1) + rows + 0.5).astype(np.float32))
+    return net
+
+
+def _src_rows(net):
+    out = []
+    for i in range(3):
+        w = net.collect_params()["yolo_outputs.%d.prediction.weight" % i].data()
+        b = net.collect_params()["yolo_outputs.%d.prediction.bias" % i].data()
+        src = []
+        for r in range(w.shape[0]):
+            v = float(w[r, 0, 0, 0]) - 1000.0 * (i + 1)
+            marked = abs(v - round(v)) < 1e-3 and 0 <= round(v) < 400 and np.all(w[r] == w[r, 0, 0, 0])
+            if marked:
+                assert abs(float(b[r]) - 0.5 - 1000.0 * (i + 1) - round(v)) < 1e-3, "weight and bias rows moved differently"
+            else:
+                assert abs(float(b[r])) < 100.0          # a fresh bias, too
+            src.append(int(round(v)) if marked else -1)
+        out.append(src)
+    return out
+
+
+def test_reset_class_moves_the_rows_the_reference_moves(golden):
+    """`net.reset_class(classes, reuse_weights)` (train_yolov3.py:728-729) against the REFERENCE's own reset_class executed on
+    marker values by the recorder (yolo3.py:1230-1302 + YOLOOutputV3.reset_class :76-129): for every form of `reuse_weights`
+    its docstring lists — names, indices, mixed, a list, None, {} — every row of the three new prediction convs holds the same
+    old row or is freshly initialised exactly where the reference leaves it so (note: the box / objectness rows are copied
+    only when at least one class is re-used), the same warnings are issued and the same ValueErrors raised, message for message."""
+    import warnings
+    g = golden["reset_class"]
+    old = g["old_classes"]
+    for case in g["cases"]:
+        reuse = case["reuse_weights"]
+        if isinstance(reuse, list) and reuse and isinstance(reuse[0], list):
+            reuse = {k: v for k, v in reuse}
+        elif reuse == [] and case["label"] == "empty_dict":
+            reuse = {}
+        net = _marked_net(old)
+        with warnings.catch_warnings(record=True) as wl:
+            warnings.simplefilter("always")
+            net.reset_class(list(case["classes"]), reuse_weights=reuse)
+        assert _src_rows(net) == case["src_rows"], case["label"]
+        assert list(net.classes) == case["classes_after"] and net._target_generator._num_class == case["merger_num_class"]
+        assert sorted(str(w.message) for w in wl) == sorted(case["warnings"]), case["label"]
+    for e in g["errors"]:
+        net = _marked_net(old)
+        with pytest.raises(ValueError) as ei:
+            net.reset_class(list(e["classes"]), reuse_weights={k: v for k, v in e["reuse_weights"]})
+        assert str(ei.value) == e["message"]
