@@ -453,6 +453,19 @@ def install():
 
 
 # ------------------------------------------------------------------------------------------------------------------
+def record_freeze_base():
+    """yolo3_darknet53(..., freeze_base=True) (wrappers.py:55-57): the parameters whose grad_req the reference sets to 'null'"""
+    from models.definitions.yolo.wrappers import yolo3_darknet53
+    net = yolo3_darknet53(["c%d" % i for i in range(20)], pretrained_base=False, k=1, freeze_base=True)
+    name_paths(net)
+    TRACE.reset()
+    net(T(3, "input"))
+    ps = net.collect_params()
+    skip = lambda k: k.rsplit(".", 1)[-1].startswith(("anchor_", "offset_"))  # noqa: E731
+    return {"grad_req_null": sorted(k for k, p in ps.items() if p.grad_req == "null" and not skip(k)),
+            "grad_req_write": sorted(k for k, p in ps.items() if p.grad_req != "null" and not skip(k))}
+
+
 def record(num_class, sync):
     """build yolo3_darknet53 as train_yolov3.py:347-360 / detect_yolo3.py:873-880 do and run one inference-mode forward"""
     import numpy as np
@@ -613,6 +626,7 @@ def main():
         "vid30": record(30, sync=False),
         "voc20_syncbn8": record(20, sync=True),
         "reset_class": record_reset_class(),
+        "freeze_base": record_freeze_base(),
     }
     with open(OUT, "w") as f:
         json.dump(doc, f, indent=1, sort_keys=False)

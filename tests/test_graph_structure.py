@@ -328,3 +328,19 @@ def test_reset_class_moves_the_rows_the_reference_moves(golden):
         with pytest.raises(ValueError) as ei:
             net.reset_class(list(e["classes"]), reuse_weights={k: v for k, v in e["reuse_weights"]})
         assert str(ei.value) == e["message"]
+
+
+def test_freeze_base_reaches_the_parameters_the_reference_freezes(golden):
+    """yolo3_darknet53(..., freeze_base=True): wrappers.py:55-57 sets grad_req = 'null' on darknet.collect_params() — every
+    tensor of the three stages, running statistics included — executed by the recorder; here: the same names."""
+    import videoyolo_amd as vy
+    g = golden["freeze_base"]
+    net = vy.yolo3_darknet53(["c%d" % i for i in range(20)], pretrained_base=False, freeze_base=True)
+    null = sorted(p.name for p in net.collect_params().values() if p.grad_req == "null")
+    write = sorted(p.name for p in net.collect_params().values() if p.grad_req != "null")
+    # the running statistics of the HEADS are 'null' in gluon by construction (BatchNorm's running_mean / running_var have
+    # grad_req 'null' always); the recorder's stand-in creates every parameter as 'write', so compare modulo those
+    heads_running = [n for n in null if not n.startswith("stages.") and n.rsplit(".", 1)[-1].startswith("running_")]
+    assert sorted(set(null) - set(heads_running)) == g["grad_req_null"]
+    assert sorted(set(write) | set(heads_running)) == g["grad_req_write"]
+    assert all(n.startswith("stages.") for n in g["grad_req_null"]) and len(g["grad_req_null"]) == 52 * 5
