@@ -325,6 +325,17 @@ class SyncBatchNorm(_Norm):
     pass
 
 
+class Dense(HybridBlock):
+    def __init__(self, units, **kw):
+        super().__init__()
+        self.units = int(units)
+        self.weight = self.params.get("weight")
+        self.bias = self.params.get("bias")
+
+    def forward(self, x):
+        return T(self.units, x.tag)
+
+
 class LeakyReLU(HybridBlock):
     def __init__(self, alpha, **kw):
         super().__init__(**kw)
@@ -401,7 +412,7 @@ KNOWN = {
     "gluoncv.loss": {"YOLOV3Loss": YOLOV3Loss},
     "mxnet.gluon": {"Block": Block, "HybridBlock": HybridBlock},
     "mxnet.gluon.nn": {"Block": Block, "HybridBlock": HybridBlock, "HybridSequential": HybridSequential, "Sequential": Sequential,
-                       "Conv2D": Conv2D, "BatchNorm": BatchNorm, "LeakyReLU": LeakyReLU},
+                       "Conv2D": Conv2D, "BatchNorm": BatchNorm, "LeakyReLU": LeakyReLU, "Dense": Dense},
     "mxnet.gluon.contrib.nn": {"SyncBatchNorm": SyncBatchNorm},
 }
 
@@ -464,6 +475,31 @@ def record_freeze_base():
     skip = lambda k: k.rsplit(".", 1)[-1].startswith(("anchor_", "offset_"))  # noqa: E731
     return {"grad_req_null": sorted(k for k, p in ps.items() if p.grad_req == "null" and not skip(k)),
             "grad_req_write": sorted(k for k, p in ps.items() if p.grad_req != "null" and not skip(k))}
+
+
+def record_backbone_names():
+    """pretrained_base: `get_darknet` loads the ImageNet classifier's file into a Darknet3D whose parameters are named
+    `features.<n>...` / `output.*` (three_darknet.py:262-264, `ignore_extra`), and wrappers.py:58 re-homes its cells under
+    `stages.<s>.<j>`.  The SAME parameter objects appear under both names: the mapping, by object identity."""
+    import models.definitions.yolo.wrappers as wr
+    captured = []
+    orig = wr.get_darknet
+
+    def capture(*a, **k):
+        net = orig(*a, **k)
+        captured.append(net)
+        return net
+    wr.get_darknet = capture
+    try:
+        net = wr.yolo3_darknet53(["c%d" % i for i in range(20)], pretrained_base=False, k=1)
+    finally:
+        wr.get_darknet = orig
+    dark = captured[0]
+    by_id = {id(p): k for k, p in dark.collect_params().items()}
+    mapping = {by_id[id(p)]: k for k, p in net.collect_params().items() if id(p) in by_id}
+    return {"classifier_to_detector": dict(sorted(mapping.items(), key=lambda kv: (int(kv[0].split(".")[1]), kv[0]))),
+            "classifier_only": sorted(k for k in by_id.values() if k not in mapping),
+            "features_children": len(dark.features)}
 
 
 def record(num_class, sync):
@@ -627,6 +663,7 @@ def main():
         "voc20_syncbn8": record(20, sync=True),
         "reset_class": record_reset_class(),
         "freeze_base": record_freeze_base(),
+        "backbone_names": record_backbone_names(),
     }
     with open(OUT, "w") as f:
         json.dump(doc, f, indent=1, sort_keys=False)

@@ -344,3 +344,17 @@ def test_freeze_base_reaches_the_parameters_the_reference_freezes(golden):
     assert sorted(set(null) - set(heads_running)) == g["grad_req_null"]
     assert sorted(set(write) | set(heads_running)) == g["grad_req_write"]
     assert all(n.startswith("stages.") for n in g["grad_req_null"]) and len(g["grad_req_null"]) == 52 * 5
+
+
+def test_pretrained_base_name_mapping(golden):
+    """`pretrained_base=True` (three_darknet.py:262-264, wrappers.py:58): the classifier checkpoint's `features.<n>...` names
+    against the detector's `stages.<s>.<j>...` names — in the reference the SAME parameter objects carry both, and the
+    recorder read the pairs off by object identity; `output.*` (the dense layer) has no counterpart and is dropped."""
+    from videoyolo_amd.model import darknet53_to_stage_names
+    g = golden["backbone_names"]
+    m = g["classifier_to_detector"]
+    assert g["features_children"] == 29 and g["classifier_only"] == ["output.bias", "output.weight"] and len(m) == 52 * 5
+    got = darknet53_to_stage_names({k: i for i, k in enumerate(list(m) + g["classifier_only"])})
+    assert {v: k for k, v in got.items()} == {i: m[k] for i, k in enumerate(m)}
+    with pytest.raises(ValueError):
+        darknet53_to_stage_names({"darknetv30_conv0_weight": 0})
