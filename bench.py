@@ -380,12 +380,25 @@ def host_fed_leg(vy, dev, dist, rank, world, size, batch, classes, steps, warmup
     h, w = src_hw
     gb = batch * world
     rng = np.random.default_rng(77)
-    # the same clip batches on every rank (a shared decoder / file; a rank touches only its slice); two distinct ones at
-    # N = 1, one at N > 1 (every rank process holds the WHOLE clip batch in host memory: 1.4 GB of 720p frames at N = 8)
-    # (random bytes are drawn for ONE rank's slice and repeated for the others: 1.4 GB of them per clip would take seconds)
-    clips = [torch.from_numpy(np.tile(rng.integers(0, 256, (batch, h, w, 3), dtype=np.uint8), (world, 1, 1, 1))).pin_memory()
-             for _ in range(2 if world == 1 else 1)]
-    clips = clips * 2   # pinned host memory: what a decoder's output buffers are (copied in without a staging copy)
+    # The clip batch of a step = `world` x the same `batch` frames (random bytes drawn once, pinned: what a decoder's output
+    # buffers are — copied in without a staging copy).  At N > 1 it is not materialised `world` times in every rank's host
+    # memory (8 x 1.4 GB of 720p frames): _RepeatedClip answers parallel.scatter_frames' slice — any rank's share — with the
+    # one pinned pool, which is exactly what the materialised tile would hold there.
+    class _RepeatedClip(object):
+        def __init__(self, pool, times):
+            self.pool, self.times = pool, times
+
+        def __len__(self):
+            return len(self.pool) * self.times
+
+        def __getitem__(self, sl):
+            lo, hi, step = sl.indices(len(self))
+            if step != 1 or hi - lo != len(self.pool) or lo % len(self.pool):
+                raise IndexError("a rank's share of %d frames, not %s" % (len(self.pool), sl))
+            return self.pool
+
+    pools = [torch.from_numpy(rng.integers(0, 256, (batch, h, w, 3), dtype=np.uint8)).pin_memory() for _ in range(2)]
+    clips = [p if world == 1 else _RepeatedClip(p, world) for p in pools]
     det = stream.HostFedDetector(net, gb, (h, w), size, depth=2, gather=True)
     kept = 0
     for i, out in enumerate(det.run(clips[i & 1] for i in range(warmup))):
