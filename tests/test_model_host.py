@@ -329,3 +329,13 @@ def test_pretrained_base_loads_a_darknet53_checkpoint_when_one_is_present(voc_cl
     os.remove(str(tmp_path / "darknet53.params"))
     with pytest.warns(UserWarning, match="no darknet53"):
         vy.yolo3_darknet53(voc_classes[:2], pretrained_base=True, root=str(tmp_path))
+
+
+def test_host_fed_detector_refuses_a_net_without_a_device(voc_classes):
+    """videoyolo_amd/stream.py has no CPU path: the pipelined detect loop needs the net on its GPU (there is no fallback to
+    fall back to), and says so instead of failing somewhere inside torch."""
+    import videoyolo_amd as vy
+    from videoyolo_amd import stream
+    net = vy.yolo3_darknet53(voc_classes, pretrained_base=False)
+    with pytest.raises(RuntimeError, match="reset_ctx"):
+        stream.HostFedDetector(net, 4, (60, 80), 96)
