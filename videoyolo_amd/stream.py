@@ -14,6 +14,12 @@ with ``depth`` buffer slots (2: double-buffered), HIP events between the streams
 the caller asks for a finished batch: batch i + 1 is copied in and batch i - 1 copied out while batch i computes.
 Nothing is computed on the host, and there is no fallback: without the HIP library every call raises.
 
+Frames that already lie in PINNED host memory are copied in directly; pageable frames go through the slot's pinned staging
+buffer first — one more host copy, and a slow one when done by a single thread (CPU stores into hipHostMalloc'ed memory:
+tools/stream_soak.py reads 593 against 1 826 frames/s at 416 x 416, batch 16, where a batch computes in 8.7 ms), so a decoder
+should own pinned output buffers.  `tools/stream_soak.py`: 1 200 batches over 2 and 3 slots, pinned and pageable, every
+result bit-equal to the synchronous path (profiles/r05_stream_soak.txt).
+
 Multi-GPU: frames shard (``parallel.scatter_frames``: this rank's slice of the clip batch, ``even_split=False`` sizes),
 no data-path collective on the way in; the only exchange is the result gather (154 KB per 64-frame slice)."""
 import ctypes
