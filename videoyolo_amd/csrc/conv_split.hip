@@ -647,8 +647,14 @@ void vy_conv_split_cfg(const ConvArgs& a, int* bm, int* bn, int* ksplit) {
 
 bool vy_conv_split_pays(const ConvArgs& a) {
   if (!vy_conv_split_supported(a)) return false;
-  const char* always = getenv("VY_SPLIT_ALWAYS");  // tests: every supported launch, however small (read per call)
-  if (always && atoi(always)) return true;
+  // tests: every supported launch, however small.  Read once per forward by the net (not per launch); per call
+  // only for ConvArgs that did not come from a net
+  int always_on = a.env_split_always_p1 - 1;
+  if (always_on < 0) {
+    const char* always = getenv("VY_SPLIT_ALWAYS");
+    always_on = always && atoi(always);
+  }
+  if (always_on) return true;
   const int cus = vy_cu_count();
   if (!vy_model_fitted(cus)) return false;  // the comparison between the two kernels was fitted on 256 CUs (conv_cost_model.h)
   int bm, bn, ks;

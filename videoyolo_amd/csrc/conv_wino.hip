@@ -387,8 +387,11 @@ static int wino_bm(const ConvArgs& a) {
 // a single frame's (the split kernel's k-split covers those).  VY_SPLIT_WINO=0: never, =2: wherever supported (tests)
 bool vy_conv_wino_pays(const ConvArgs& a) {
   if (!vy_conv_wino_supported(a)) return false;
-  const char* sw = getenv("VY_SPLIT_WINO");  // read per call (tests switch it)
-  const int mode = sw ? atoi(sw) : 1;
+  int mode = a.env_wino_mode_p1 - 1;  // read once per forward by the net; per call only for hand-made ConvArgs
+  if (mode < 0) {
+    const char* sw = getenv("VY_SPLIT_WINO");
+    mode = sw ? atoi(sw) : 1;
+  }
   if (mode == 0) return false;
   if (mode == 2) return true;
   const int cus = vy_cu_count();

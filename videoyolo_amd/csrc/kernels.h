@@ -59,6 +59,9 @@ struct ConvArgs {
   // conv_wino.hip only: this conv's weights as four Winograd-transformed, pre-split image sets (vy_launch_wino_weights);
   // nullable
   const void* w_wino;
+  // the test switches VY_SPLIT_ALWAYS / VY_SPLIT_WINO as the net read them ONCE at the start of this forward / step
+  // (value + 1; 0: not read — vy_conv_*_pays read the environment themselves, e.g. for a probe's hand-made ConvArgs)
+  int env_split_always_p1, env_wino_mode_p1;
 };
 #define VY_SK_PARTIAL_BYTES (32u << 20)  // 512 blocks x 128x128 fp32 (the largest instance: 2 blocks per CU x 256 CUs)
 #define VY_SK_FLAGS 2048

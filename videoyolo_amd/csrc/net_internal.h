@@ -98,6 +98,15 @@ struct vy_net {
   // for inference at the same size) but train.hip's refresh_split_images rebuilds only the forward and data-gradient sets —
   // only forward() below, which does rebuild them, may clear it
   bool wino_dirty = true;
+  // VY_SPLIT_ALWAYS / VY_SPLIT_WINO (test switches of the per-launch choice), read once at the start of every forward /
+  // training step (refresh_env) instead of by every launch's vy_conv_*_pays; -1: not read yet
+  int env_split_always = -1, env_wino_mode = -1;
+  void refresh_env() {
+    const char* a = getenv("VY_SPLIT_ALWAYS");
+    const char* w = getenv("VY_SPLIT_WINO");
+    env_split_always = a && atoi(a) ? 1 : 0;
+    env_wino_mode = w ? atoi(w) : 1;
+  }
   size_t wsplit_off = 0;
   struct VyTrain* train = nullptr;  // training planner state, owned by train.hip
 
@@ -448,6 +457,8 @@ struct vy_net {
     a.dgrad = 0;
     a.w_split = c.split_off >= 0 ? dev_ws + wsplit_off + c.split_off : nullptr;
     a.w_wino = c.wino_off >= 0 ? dev_ws + wsplit_off + c.wino_off : nullptr;
+    a.env_split_always_p1 = env_split_always + 1;
+    a.env_wino_mode_p1 = env_wino_mode + 1;
     a.splitk_slabs = reinterpret_cast<float*>(dev_ws + sk_off + al((size_t)VY_SK_FLAGS * sizeof(unsigned)));
     a.splitk_bytes = VY_SK_PARTIAL_BYTES;
     set_sk(a);
@@ -513,6 +524,7 @@ struct vy_net {
   int forward(const float* x, float* ids, float* scores, float* bboxes, int32_t* keep_idx, hipStream_t s,
               Hook&& hook) {
     if (int rc = check_ready()) return rc;
+    refresh_env();
     const bool nms_on = nms_thresh > 0.f && nms_thresh < 1.f;  // yolo3.py:1197
     FoldDesc* fd = reinterpret_cast<FoldDesc*>(dev_ws + fold_desc_off);
     if (!fold_uploaded) {

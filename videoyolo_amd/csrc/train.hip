@@ -419,6 +419,7 @@ static int launch_conv(const ConvArgs& a, hipStream_t s) {
 int forward_train(const TrainCtx& c, const float* x) {
   vy_net* net = c.net;
   const int B = net->B;
+  net->refresh_env();
   if (int rc = refresh_split_images(c)) return rc;
   for (size_t ci = 0; ci < net->convs.size(); ++ci) {
     const ConvT& cv = net->convs[ci];
@@ -555,6 +556,8 @@ BwdDgrad make_dgrad(const TrainCtx& c, const ConvT& cv, const float* dzp, int dz
   a.o_co = cv.in_co;
   a.ups = 1;
   a.dgrad = 1;
+  a.env_split_always_p1 = net->env_split_always + 1;  // (as read by this step's forward)
+  a.env_wino_mode_p1 = net->env_wino_mode + 1;
   net->set_sk(a);
   {  // split-fp32 conv mode: this conv's data-gradient weight images and the split-K scratch (the stream-K region)
     const size_t ci = (size_t)(&cv - net->convs.data());
