@@ -360,6 +360,101 @@ def train_leg(vy, dev, dist, rank, world, size, batch, classes, steps, warmup, s
     return out
 
 
+MULTISCALE_SIZES = tuple(32 * x for x in range(10, 20))  # train_yolov3.py:266 `x * 32 for x in range(10, 20)`: 320 ... 608
+
+
+def multiscale_leg(vy, dev, dist, rank, world, batch, classes, interval, warmup, sizes=MULTISCALE_SIZES, seed=233,
+                   conv_mode="exact"):
+    """The reference's DEFAULT training mode (train_yolov3.py:258-271: `RandomTransformDataLoader(transform_fns, ...,
+    interval=10)` unless --no_random_shape): one net, one trainer, the input side drawn from 320 ... 608 and changed every
+    `interval` batches.  Here: every one of the ten sizes once, in a seeded random order (the same on every rank: the
+    loader picks ONE transform per batch, all devices train the same size), `interval` steps each.  Timed like
+    also_train416 — barrier + synchronize around the WHOLE sequence, max over ranks — so every re-plan (workspace bind,
+    border zeroing, tile choices for the new shapes) is inside the clock; per size a synchronize on both sides of the
+    re-plan and of its window gives `replan_ms` and the window's frames/s (rank 0's view).  The warm-up runs at the LARGEST
+    size, so the workspace has its final extent before the clock starts (what the first epoch does for every later one)."""
+    import random
+    import torch
+    from videoyolo_amd import autograd, targets, parallel
+    multi = world > 1 or parallel.collectives_active()
+    net = vy.yolo3_darknet53(["c%d" % i for i in range(classes)], pretrained_base=False)
+    net.initialize(init="synthetic", seed=233)
+    net.collect_params().reset_ctx(dev)
+    net.set_conv_mode(conv_mode)
+    trainer = vy.Trainer(net.collect_params(), 'sgd', {'learning_rate': 1e-3, 'wd': 5e-4, 'momentum': 0.9})
+    if multi:
+        trainer.enable_overlap()
+    gb = batch * world
+    order = list(sizes)
+    random.Random(seed).shuffle(order)
+    g = torch.Generator(device="cpu").manual_seed(4233 + rank)
+    tgen = targets.YOLOV3PrefetchTargetGenerator(classes)
+    data = {}
+    for s in sizes:
+        x = torch.randn((batch, 3, s, s), generator=g, dtype=torch.float32).to(dev)
+        gt_boxes, gt_ids = targets.synthetic_gt(batch, s, classes, m=8, seed=100 + rank)
+        tg = tgen(s, s, gt_boxes, gt_ids)
+        data[s] = (x, [torch.as_tensor(t).to(dev) for t in (gt_boxes,) + tuple(tg)])
+
+    def step(s):
+        x, dv = data[s]
+        with autograd.record():
+            losses = net(x, *dv)
+            autograd.backward([losses[0] + losses[1] + losses[2] + losses[3]])
+        trainer.step(gb)
+        return losses
+
+    for _ in range(max(1, warmup)):
+        step(max(sizes))
+    rows = []
+    _barrier(dist, torch)
+    t0 = time.perf_counter()
+    for s in order:
+        ta = time.perf_counter()
+        with torch.cuda.device(dev):
+            net._ensure_plan(batch, s, s, train=True)     # what the first step at a new size does anyway: timed alone
+        torch.cuda.synchronize()
+        tb = time.perf_counter()
+        step(s)
+        torch.cuda.synchronize()
+        tc = time.perf_counter()
+        for _ in range(interval - 1):
+            losses = step(s)
+        torch.cuda.synchronize()
+        td = time.perf_counter()
+        rows.append((s, tb - ta, tc - tb, td - tc, td - ta, float(sum(l.sum() for l in losses).item() / batch)))
+    _barrier(dist, torch)
+    dt = _max_over_ranks(time.perf_counter() - t0, dist, torch, dev)
+    nsteps = interval * len(order)
+    per_size = {}
+    g416 = FWD_GFLOP_PER_FRAME[(416, 20)]
+    for s, replan, first, rest, window, loss in rows:
+        steady = rest / max(1, interval - 1)
+        gf = g416 * (s / 416.0) ** 2   # every conv's M scales with the pixel count; prediction convs differ by < 0.1 %
+        fps_w = gb * interval / window
+        per_size[str(s)] = {
+            "frames_per_s": fps_w, "steady_ms_per_step": 1e3 * steady, "replan_ms": 1e3 * replan,
+            "first_step_extra_ms": 1e3 * (first - steady), "replan_share_of_window": replan / window,
+            "frac_whole_step": gb / world / steady * 3 * gf / 1e3 / FP32_MFMA_PEAK_TFLOPS, "loss_rank0": loss}
+    replan_total = sum(r[1] for r in rows)
+    gf_total = sum(g416 * (s / 416.0) ** 2 * 3 * batch * interval for s in order)
+    out = {"frames_per_s": gb * nsteps / dt, "ms_per_step": 1e3 * dt / nsteps, "n_gpus": world, "per_gpu_batch": batch,
+           "global_batch": gb, "classes": classes, "sizes_in_order": order, "interval": interval, "steps": nsteps,
+           "warmup": "%d step(s) at %d" % (max(1, warmup), max(sizes)), "dtype": "f32" if conv_mode == "exact" else SPLIT_DTYPE,
+           "replan_ms_total": 1e3 * replan_total, "replan_share": replan_total / dt,
+           "replan_ms_max": 1e3 * max(r[1] for r in rows),
+           "frac": gf_total / dt / 1e3 / FP32_MFMA_PEAK_TFLOPS,
+           "backend": dist.get_backend() if dist is not None else None, "per_size": per_size,
+           "note": "timed region = the whole ten-window sequence incl. every re-plan; per-size figures are rank 0's, bracketed by "
+                   "synchronize (20 extra synchronizes in %d steps); conv-only fractions and tile choices per size: "
+                   "profiles/r06_multiscale_layers.txt (tools/multiscale_layers.sh)" % nsteps}
+    del trainer, net, data
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()
+    return out
+
+
 def host_fed_leg(vy, dev, dist, rank, world, size, batch, classes, steps, warmup, src_hw, conv_mode="exact", obj_bias=0.0,
                  resident_fps=None):
     """The reference's detect loop (detect_yolo3.py:209-233) fed from the HOST: per step one clip batch of world x batch
@@ -536,6 +631,9 @@ def main():
     ap.add_argument("--vid-size", type=int, default=608, help="also_vid608: network input size (tests use small ones)")
     ap.add_argument("--train-steps", type=int, default=20, help="timed steps of each training leg (20: a 0.6 s window; 10 was short enough for one host hiccup to cost 10 %)")
     ap.add_argument("--train-size", type=int, default=416)
+    ap.add_argument("--no-multiscale-leg", action="store_true", help="skip also_train_multiscale (the reference's default training mode)")
+    ap.add_argument("--multiscale-interval", type=int, default=10, help="steps per size (train_yolov3.py:270 interval=10)")
+    ap.add_argument("--multiscale-sizes", default=",".join(str(v) for v in MULTISCALE_SIZES), help="tests use small ones")
     ap.add_argument("--train-batch", type=int, default=16, help="frames per GPU of also_train416")
     ap.add_argument("--syncbn-size", type=int, default=608)
     ap.add_argument("--syncbn-batch", type=int, default=8, help="frames per GPU of also_syncbn608")
@@ -864,6 +962,15 @@ def main():
             leg["traffic"] = None
             leg["traffic_note"] = train_traffic_note
         result["also_train416"] = leg
+        if not args.no_multiscale_leg:
+            ms = multiscale_leg(vy, dev, dist, rank, world, args.train_batch, args.classes, args.multiscale_interval, args.warmup,
+                                sizes=tuple(int(v) for v in args.multiscale_sizes.split(",")))
+            ms["workload"] = ("the reference's DEFAULT training mode (train_yolov3.py:258-271, RandomTransformDataLoader interval=%d): "
+                              "BASELINE.json configs[2]'s step with the input side changing through %s, per-GPU batch %d"
+                              % (args.multiscale_interval, args.multiscale_sizes, args.train_batch))
+            ms["vs_fixed_416"] = {"frames_per_s_416_window": ms["per_size"].get("416", {}).get("frames_per_s"),
+                                  "also_train416_frames_per_s": leg["frames_per_s"]}
+            result["also_train_multiscale"] = ms
         if not args.no_split_leg:
             # the same training step in conv mode split_bf16x3_train (forward, data and weight gradients on the bf16 matrix
             # core; NOT the parity path): separately reported, like also_infer608_split

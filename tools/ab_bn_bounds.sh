@@ -1,4 +1,6 @@
 #!/bin/bash
+# NEEDS a measurement build of the library (the shipped one never reads VY_TRAIN_ABL):
+#   VY_BUILD_EXTRA_FLAGS=-DVY_TRAIN_ABL_BUILD python -m videoyolo_amd.build --force     (rebuild without it afterwards)
 # What could fusing the BatchNorm passes of the training step into the neighbouring conv launches return AT MOST?
 # The step with those launches simply skipped (VY_TRAIN_ABL, train.hip; results are garbage), exact and split mode.
 # bits: 1 bn_bwd_reduce (+ finalize)   2 forward bn_apply   4 bn_bwd_apply

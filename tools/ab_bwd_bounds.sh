@@ -1,4 +1,6 @@
 #!/bin/bash
+# NEEDS a measurement build of the library (the shipped one never reads VY_TRAIN_ABL):
+#   VY_BUILD_EXTRA_FLAGS=-DVY_TRAIN_ABL_BUILD python -m videoyolo_amd.build --force     (rebuild without it afterwards)
 # Which stream of the backward pass holds the training step?  VY_TRAIN_ABL=8: no weight-gradient kernels (side stream),
 # 16: no data-gradient kernels (main stream), 24: neither, 31: neither and no BatchNorm passes (forward + fixed parts only)
 R=${GRAFT_REPO_ROOT:-.}

@@ -21,6 +21,8 @@ HEADERS = [os.path.join(CSRC, "kernels.h"), os.path.join(CSRC, "net_internal.h")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
          "-fhip-fp32-correctly-rounded-divide-sqrt", "-Wall", "-Wno-unused-function", "-Wno-inline-asm"]
+# measurement builds only (tools/ab_bn_bounds.sh: VY_BUILD_EXTRA_FLAGS=-DVY_TRAIN_ABL_BUILD); use with --force
+FLAGS += os.environ.get("VY_BUILD_EXTRA_FLAGS", "").split()
 
 
 def _stale(target, deps):

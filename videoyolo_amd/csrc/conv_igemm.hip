@@ -31,6 +31,7 @@
 // 128x128 tile: 66 KiB of LDS -> 2 blocks / CU, 64 accumulator VGPRs / lane.
 // dgrad reads W as the [k][n] operand: its LDS tile is 32 k-rows of BN contiguous floats, read with
 // ds_read_b32 (32 consecutive floats per half-wave: conflict-free without a swizzle).
+#include <atomic>
 #include <cstdio>
 #include <algorithm>
 #include <cstdlib>
@@ -635,20 +636,32 @@ static int resident_blocks(K kernel, int threads) {
 }
 // CUs of the current device (per device, queried once each; VY_CU_COUNT=n overrides it: tests of the cost models'
 // behaviour on a chip they were not fitted on).  256 when there is no device to ask (host-only callers)
-int vy_cu_count() {
+int vy_cu_count_of(int dev) {
   static const int forced = getenv("VY_CU_COUNT") ? atoi(getenv("VY_CU_COUNT")) : 0;
   if (forced > 0) return forced;
-  static int cache[64];
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return VY_MODEL_CUS;
-  if (!cache[dev]) {
-    int c = 0;
+  static std::atomic<int> cache[64];  // (several host threads may drive their own nets: relaxed atomics, idempotent fill)
+  if (dev < 0 || dev >= 64) return VY_MODEL_CUS;
+  int c = cache[dev].load(std::memory_order_relaxed);
+  if (!c) {
     if (hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || c < 1) c = VY_MODEL_CUS;
-    cache[dev] = c;
+    cache[dev].store(c, std::memory_order_relaxed);
   }
-  return cache[dev];
+  return c;
 }
-static int cu_count() { return vy_cu_count(); }
+int vy_cu_count() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return vy_cu_count_of(-1);
+  return vy_cu_count_of(dev);
+}
+int vy_cu_count_of_ptr(const void* p) {
+  hipPointerAttribute_t at;
+  if (!p || hipPointerGetAttributes(&at, p) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  if (at.type != hipMemoryTypeDevice) return 0;
+  return vy_cu_count_of(at.device);
+}
 
 // ---- stream-K topology check --------------------------------------------------------------------------------------
 // The stream-K schedule (sk_schedule.h) is built for the MI355X in SPX mode: 256 CUs, 8 XCDs, workgroups dealt round-robin
@@ -678,7 +691,7 @@ int vy_sk_verify_topology(unsigned* scratch_dev, hipStream_t s) {
   bool ok = hipGetLastError() == hipSuccess &&
             hipMemcpyAsync(host, scratch_dev, sizeof host, hipMemcpyDeviceToHost, s) == hipSuccess &&
             hipMemsetAsync(scratch_dev, 0, sizeof host, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
-  ok = ok && cu_count() == 256;  // the cost model's rounds and the schedule's shares are per 256 CUs
+  ok = ok && vy_cu_count_of(dev) == 256;  // the cost model's rounds and the schedule's shares are per 256 CUs
   for (int b = 0; ok && b < NB; ++b) ok = host[b] < 8u && host[b] == host[b & 7];
   for (int i = 0; ok && i < 8; ++i)
     for (int j = 0; j < i; ++j) ok = ok && host[i] != host[j];
@@ -725,7 +738,7 @@ static hipError_t launch_cfg(const ConvArgs& a, hipStream_t s, bool* sk_query = 
     static const int res_f = resident_blocks(conv_igemm_kernel<BM, BN, WM, WN, false, NS, true>, WM * WN * 64);
     static const int res_d = resident_blocks(conv_igemm_kernel<BM, BN, WM, WN, true, NS, true>, WM * WN * 64);
     const int sk_slots = sk_switches().slots;
-    const int cus = cu_count();
+    const int cus = vy_args_cus(a);
     // blocks per CU: as many as fit, but never so many that a share is shorter than one tile (a share is at most
     // [head][whole tiles][tail]).  344 tiles (the 13x13 maps at batch 16): ONE block per CU with 1.34 tiles each, where
     // the plain launch leaves 88 CUs with two tiles and 168 with one
@@ -778,7 +791,7 @@ static void select_cfg(const ConvArgs& a, int* bm, int* bn) {
   }
   const double K = (double)a.ntaps * a.Kc;
   bool sk_unused;
-  double best = vy_select_tile(a.M, a.N, K, sk_policy(a), bm, bn, &sk_unused, cu_count());
+  double best = vy_select_tile(a.M, a.N, K, sk_policy(a), bm, bn, &sk_unused, vy_args_cus(a));
   // 16x16 wave tiles (conv_small.hip; block tile 32 x {32, 64}): OFF by default.  Measured on the MI355X (round 3,
   // profiles/r03_negative_results.txt): bit-exact, but 1.9 - 2.0x SLOWER than the 64x64 tile on the batch-1 3x3 layers it
   // was built for (76x76: 78-85 vs 42 us, 38x38: 85-88 vs 43, 19x19: 98-128 vs 77) — a 32-channel sub-step of a 32x32
@@ -810,7 +823,7 @@ double vy_conv_predict_us(const ConvArgs& a) {
   if (a.N <= 32) return 0.0;  // own tile, no model: never handed to the split kernel (cout % 64 != 0 anyway)
   int bm, bn;
   bool sk;
-  return vy_select_tile(a.M, a.N, (double)a.ntaps * a.Kc, sk_policy(a), &bm, &bn, &sk, cu_count());
+  return vy_select_tile(a.M, a.N, (double)a.ntaps * a.Kc, sk_policy(a), &bm, &bn, &sk, vy_args_cus(a));
 }
 
 int vy_conv_tiles_m(const ConvArgs& a) {

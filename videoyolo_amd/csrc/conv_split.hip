@@ -642,7 +642,7 @@ void vy_conv_split_cfg(const ConvArgs& a, int* bm, int* bn, int* ksplit) {
     *ksplit = (int)std::max<long long>(1, std::min<long long>(std::min<long long>(std::max(1, fks), split_max_ksplit(a)), t_all / 6));
     return;
   }
-  vy_predict_split(a.M, a.N, (double)a.ntaps * a.Kc, (int)std::min<long long>(split_max_ksplit(a), 64), bm, bn, ksplit, vy_cu_count());
+  vy_predict_split(a.M, a.N, (double)a.ntaps * a.Kc, (int)std::min<long long>(split_max_ksplit(a), 64), bm, bn, ksplit, vy_args_cus(a));
 }
 
 bool vy_conv_split_pays(const ConvArgs& a) {
@@ -655,7 +655,7 @@ bool vy_conv_split_pays(const ConvArgs& a) {
     always_on = always && atoi(always);
   }
   if (always_on) return true;
-  const int cus = vy_cu_count();
+  const int cus = vy_args_cus(a);
   if (!vy_model_fitted(cus)) return false;  // the comparison between the two kernels was fitted on 256 CUs (conv_cost_model.h)
   int bm, bn, ks;
   return vy_predict_split(a.M, a.N, (double)a.ntaps * a.Kc, (int)std::min<long long>(split_max_ksplit(a), 64), &bm, &bn, &ks, cus) <

@@ -394,7 +394,7 @@ bool vy_conv_wino_pays(const ConvArgs& a) {
   }
   if (mode == 0) return false;
   if (mode == 2) return true;
-  const int cus = vy_cu_count();
+  const int cus = vy_args_cus(a);
   if (!vy_model_fitted(cus)) return false;  // fitted on 256 CUs (conv_cost_model.h)
   const long long pairs = (long long)a.B * a.LH * ((a.LW + 1) / 2);
   const double t_wino = vy_predict_wino(pairs, a.N, a.Kc, cus);

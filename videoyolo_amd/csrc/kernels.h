@@ -62,6 +62,10 @@ struct ConvArgs {
   // the test switches VY_SPLIT_ALWAYS / VY_SPLIT_WINO as the net read them ONCE at the start of this forward / step
   // (value + 1; 0: not read — vy_conv_*_pays read the environment themselves, e.g. for a probe's hand-made ConvArgs)
   int env_split_always_p1, env_wino_mode_p1;
+  // CUs of the device this launch goes to, as the net resolved them ONCE (vy_net::cus: at its first sizing call, checked
+  // against the workspace's device at bind time) — every cost-model choice of a net counts rounds in the same chip whatever
+  // the calling thread's current device is.  0: not set (a probe's hand-made ConvArgs): vy_cu_count() of the current device
+  int cus;
 };
 #define VY_SK_PARTIAL_BYTES (32u << 20)  // 512 blocks x 128x128 fp32 (the largest instance: 2 blocks per CU x 256 CUs)
 #define VY_SK_FLAGS 2048
@@ -74,7 +78,10 @@ hipError_t vy_launch_conv_s16(const ConvArgs& a, int bm, int bn, hipStream_t s);
 int vy_conv_tiles_m(const ConvArgs& a);
 void vy_conv_cfg(const ConvArgs& a, int* bm, int* bn);  // block tile the launch will use
 double vy_conv_predict_us(const ConvArgs& a);             // the cost model's time for the launch (conv_cost_model.h)
-int vy_cu_count();                                        // CUs of the current device (what the cost models count rounds in)
+int vy_cu_count();                                        // CUs of the CURRENT device (nets resolve theirs once: vy_net::cus)
+int vy_cu_count_of(int device);                           // ... of a given device ordinal
+int vy_cu_count_of_ptr(const void* dev_ptr);              // ... of the device that owns an allocation (0: not a device pointer)
+static inline int vy_args_cus(const ConvArgs& a) { return a.cus > 0 ? a.cus : vy_cu_count(); }
 bool vy_conv_streamk(const ConvArgs& a);                  // ... and whether it will be a stream-K launch (label "<BM>x<BN>sk")
 
 // stream-K is enabled per net only after this has seen the MI355X's SPX placement (8 XCDs, blocks L and L + 8 on one

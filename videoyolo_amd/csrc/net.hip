@@ -152,6 +152,7 @@ static int check_shape(int32_t batch, int32_t h, int32_t w) {
 
 size_t vy_net_workspace_bytes(const vy_net* net, int32_t batch, int32_t height, int32_t width) {
   if (!net || check_shape(batch, height, width)) return 0;
+  const_cast<vy_net*>(net)->resolve_cus();
   return const_cast<vy_net*>(net)->plan(batch, height, width, false, net->keep_activations);
 }
 
@@ -159,6 +160,7 @@ int vy_net_bind_workspace(vy_net* net, void* dev_ws, size_t bytes, int32_t batch
                           void* stream) {
   if (!net || !dev_ws) return fail(VY_ERR_INVALID, "null argument");
   if (int rc = check_shape(batch, height, width)) return rc;
+  if (int rc = net->bind_cus(dev_ws)) return rc;
   const size_t need = net->plan(batch, height, width, false, net->keep_activations);
   if (bytes < need) return fail(VY_ERR_INVALID, "workspace too small: %zu < %zu bytes", bytes, need);
   net->plan(batch, height, width, true, net->keep_activations);

@@ -101,6 +101,24 @@ struct vy_net {
   // VY_SPLIT_ALWAYS / VY_SPLIT_WINO (test switches of the per-launch choice), read once at the start of every forward /
   // training step (refresh_env) instead of by every launch's vy_conv_*_pays; -1: not read yet
   int env_split_always = -1, env_wino_mode = -1;
+  // CUs of THIS net's device: resolved once, by the first sizing / bind call, from the calling thread's current device —
+  // and checked at every bind against the device that owns the workspace (bind_cus below), so that a C-ABI caller whose
+  // current device differs between vy_net_*workspace_bytes and vy_net_bind_* gets an error instead of a plan sized for
+  // one chip and bound on another.  Every cost-model choice reads this through ConvArgs::cus.
+  int cus = 0;
+  int resolve_cus() {
+    if (!cus) cus = vy_cu_count();
+    return cus;
+  }
+  int bind_cus(const void* ws) {
+    const int sized = resolve_cus();
+    const int owner = vy_cu_count_of_ptr(ws);
+    if (owner && owner != sized)
+      return fail(VY_ERR_STATE,
+                  "the workspace lives on a device with %d CUs but this net sized its plan for %d (the calling thread's current "
+                  "device at the first vy_net_*workspace_bytes call): size and bind with the same current device", owner, sized);
+    return 0;
+  }
   void refresh_env() {
     const char* a = getenv("VY_SPLIT_ALWAYS");
     const char* w = getenv("VY_SPLIT_WINO");
@@ -459,6 +477,7 @@ struct vy_net {
     a.w_wino = c.wino_off >= 0 ? dev_ws + wsplit_off + c.wino_off : nullptr;
     a.env_split_always_p1 = env_split_always + 1;
     a.env_wino_mode_p1 = env_wino_mode + 1;
+    a.cus = cus;
     a.splitk_slabs = reinterpret_cast<float*>(dev_ws + sk_off + al((size_t)VY_SK_FLAGS * sizeof(unsigned)));
     a.splitk_bytes = VY_SK_PARTIAL_BYTES;
     set_sk(a);

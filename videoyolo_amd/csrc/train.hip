@@ -118,10 +118,20 @@ bool g_labels_done = false;
 // fusing them into the neighbouring conv launches could return — bit 1: bn_bwd_reduce (+ its finalize), 2: the forward
 // bn_apply, 4: bn_bwd_apply; and, to see which stream of the backward pass holds the step, 8: no weight-gradient
 // kernels, 16: no data-gradient kernels.  The step then computes garbage; nothing else reads this.
+// Compiled in ONLY with -DVY_TRAIN_ABL_BUILD (the A/B scripts build their own library): the shipped library never reads
+// the variable, so a leftover VY_TRAIN_ABL in somebody's environment cannot silently turn a training run into garbage.
+#ifdef VY_TRAIN_ABL_BUILD
 static int train_abl() {
-  static const int v = getenv("VY_TRAIN_ABL") ? atoi(getenv("VY_TRAIN_ABL")) : 0;
+  static const int v = [] {
+    const int e = getenv("VY_TRAIN_ABL") ? atoi(getenv("VY_TRAIN_ABL")) : 0;
+    if (e) fprintf(stderr, "libvyolo (VY_TRAIN_ABL_BUILD): VY_TRAIN_ABL=%d — training launches are being SKIPPED, gradients are garbage\n", e);
+    return e;
+  }();
   return v;
 }
+#else
+static constexpr int train_abl() { return 0; }
+#endif
 
 constexpr int kBwdChunk = 64;  // pixels per partial-sum block of the bias-gradient reductions (and the scratch bound)
 
@@ -209,7 +219,7 @@ size_t train_plan(vy_net* net, int b, int h, int w, bool commit) {
       // cheapest (splits, k_per_split) under that model is taken; a split is >= 256 pixels.
       long long best_k = ((M + 31) / 32) * 32, best_sp = 1;
       double best_cost = 1e300;
-      const long long held = 2ll * vy_cu_count();  // blocks the device holds at a time (512 on the MI355X)
+      const long long held = 2ll * net->resolve_cus();  // blocks the net's device holds at a time (512 on the MI355X)
       for (long long k = 256; k <= ((M + 31) / 32) * 32; k += 32) {
         const long long sp_k = (M + k - 1) / k;
         const long long rounds = (tiles * sp_k + held - 1) / held;
@@ -558,6 +568,7 @@ BwdDgrad make_dgrad(const TrainCtx& c, const ConvT& cv, const float* dzp, int dz
   a.dgrad = 1;
   a.env_split_always_p1 = net->env_split_always + 1;  // (as read by this step's forward)
   a.env_wino_mode_p1 = net->env_wino_mode + 1;
+  a.cus = net->cus;
   net->set_sk(a);
   {  // split-fp32 conv mode: this conv's data-gradient weight images and the split-K scratch (the stream-K region)
     const size_t ci = (size_t)(&cv - net->convs.data());
@@ -882,6 +893,7 @@ int vy_net_bind_train(vy_net* net, void* dev_ws, size_t bytes, int32_t batch, in
   if (!net || !dev_ws || !dev_grads || !dev_momentum) return fail(VY_ERR_INVALID, "null argument");
   if (int rc = check_train_shape(height, width)) return rc;
   if (vy_net_workspace_bytes(net, batch, height, width) == 0) return VY_ERR_INVALID;
+  if (int rc = net->bind_cus(dev_ws)) return rc;
   const size_t need = train_plan(net, batch, height, width, false);
   if (bytes < need) return fail(VY_ERR_INVALID, "training workspace too small: %zu < %zu bytes", bytes, need);
   train_plan(net, batch, height, width, true);

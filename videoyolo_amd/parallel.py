@@ -236,7 +236,12 @@ def gather_detections(ids, scores, bboxes, total=None):
     if total is not None:
         sizes = split_sizes(int(total), w)
         if sizes[r] != int(packed.shape[0]):
-            raise ValueError("rank %d holds %d frames of a batch of %d, expected %d" % (r, packed.shape[0], total, sizes[r]))
+            # only THIS rank can see that its slice is wrong: the peers are about to enter the all-gather.  Abort the
+            # group so that they error out at once instead of waiting for the timeout, then raise
+            e = ValueError("rank %d holds %d frames of a batch of %d, expected %d" % (r, packed.shape[0], total, sizes[r]))
+            if w > 1:
+                fail_group(e)
+            raise e
     else:
         sizes = [None] * w
         dist.all_gather_object(sizes, int(packed.shape[0]))

@@ -45,6 +45,9 @@ class HostFedDetector(object):
         if net._device is None:
             raise RuntimeError("net.collect_params().reset_ctx(device) first")
         self.net, self.size, self.depth = net, int(size), int(depth)
+        if self.depth < 1:
+            raise ValueError("depth must be at least 1 slot, got %r" % (depth,))
+        depth = self.depth
         self.dev = net._device
         self.world, self.rank = parallel.world_size(), parallel.rank()
         self.global_batch = int(global_batch)
@@ -81,6 +84,13 @@ class HostFedDetector(object):
         if self._busy[k]:
             raise RuntimeError("slot %d still holds an uncollected batch: call result() before submitting %d more"
                                % (k, self.depth))
+        # the checks every rank evaluates identically come FIRST: a wrong clip batch raises on all ranks together, before
+        # any of them has entered the result gather (a one-sided raise would leave the others waiting in the collective)
+        if len(clip_batch) != self.global_batch:
+            raise ValueError("expected a clip batch of %d frames, got %d" % (self.global_batch, len(clip_batch)))
+        dt = getattr(clip_batch, "dtype", None)
+        if dt is not None and str(dt).replace("torch.", "") != "uint8":
+            raise TypeError("frames must be uint8 (decoded images), got %s" % dt)
         mine = parallel.scatter_frames(clip_batch, self.rank, self.world)
         if tuple(mine.shape) != (self.b, self.h, self.w, 3):
             raise ValueError("expected %s uint8 frames for this rank, got %s" % ((self.b, self.h, self.w, 3), tuple(mine.shape)))
@@ -138,6 +148,8 @@ class HostFedDetector(object):
         """Wait for the batch in ``slot`` and return (ids (B,R,1), scores (B,R,1), bboxes (B,R,4)) as numpy views of the
         pinned output buffer (valid until the slot is submitted again).  B = the whole clip batch on rank 0 when gathering
         (the other ranks get None), this rank's slice otherwise."""
+        if not (0 <= int(slot) < self.depth) or not self._busy[slot]:
+            raise RuntimeError("slot %r holds no submitted batch (never submitted, or its result was already collected)" % (slot,))
         self.e_out[slot].synchronize()
         self._busy[slot] = False
         if self.gather and self.rank != 0:
