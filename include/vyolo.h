@@ -190,6 +190,18 @@ int32_t vy_net_num_anchors(const vy_net* net);
 int vy_net_forward_infer(vy_net* net, const float* x, float* ids, float* scores, float* bboxes,
                          int32_t* keep_idx, void* stream);
 
+/* The detection tail ALONE, on caller-supplied prediction-conv outputs: YOLOOutputV3.hybrid_forward's inference branch
+ * (yolo3.py:158-197: decode, x C tile, class-major rows) for the three scales, their concat (yolo3.py:1195), box_nms and
+ * the slice (yolo3.py:1197-1206) — what `net.yolo_outputs[i](pred)` + `F.contrib.box_nms` compute in the reference.
+ *   head_i   device, (batch, 3*(5+C), H_i, W_i) fp32 NCHW for strides 32, 16, 8 (the layout vy_net_read_head returns),
+ *            H_i x W_i of the bound workspace's plan
+ * Outputs as vy_net_forward_infer (nms_thresh outside (0,1): the (B, N*C, 6) detection tensor itself).  This is the
+ * operator-level door the golden-vector kit uses (tests/golden/make_mxnet_goldens.py: hand-built logits decide threshold
+ * strictness, tie order and the top-k cut on the SAME kernels a forward runs); it overwrites the head planes of the
+ * workspace.  Asynchronous on `stream`. */
+int vy_net_detect_heads(vy_net* net, const float* head0, const float* head1, const float* head2, float* ids,
+                        float* scores, float* bboxes, int32_t* keep_idx, void* stream);
+
 /* Debug / parity taps (asynchronous on `stream`, valid after a forward on the same stream):
  * copy head i's prediction-conv output (yolo3.py:154 `pred`) to dst as (batch, 3*(5+C), H_i, W_i)
  * NCHW — i = 0,1,2 for strides 32,16,8. */

@@ -266,6 +266,14 @@ class OracleYolo3:
                       None, self.p["yolo_outputs.%d.prediction.bias" % i], leaky=False)
         if raw_only:
             return pred
+        return self.decode(pred, i)
+
+    # yolo3.py:158-197: the decode of ONE scale's prediction-conv output `pred` (B, A*(5+C), H, W) — what
+    # `net.yolo_outputs[i](pred)` returns outside autograd; i = 0, 1, 2 for strides 32, 16, 8
+    def decode(self, pred, i):
+        C, A = self.C, 3
+        P = 5 + C
+        pred = _c(pred)
         B, _, H, W = pred.shape
         anchors = np.array(ANCHORS[::-1][i], np.float32).reshape(1, 1, A, 2)  # yolo3.py:1013
         stride = np.float32(STRIDES[::-1][i])
@@ -302,6 +310,10 @@ class OracleYolo3:
             up = up[:, :, :route_now.shape[2], :route_now.shape[3]]  # slice_like, yolo3.py:1177
             x = np.concatenate([up, route_now], axis=1)
         return outs
+
+    def detections_from_heads(self, heads):
+        """yolo3.py:1195 on caller-supplied prediction-conv outputs (stride 32, 16, 8): (B, N*C, 6)."""
+        return np.concatenate([self.decode(h, i) for i, h in enumerate(heads)], axis=1)
 
     def raw_heads(self, x):
         """Per-scale prediction-conv outputs (B, A*(5+C), H, W), order stride 32, 16, 8."""

@@ -20,6 +20,20 @@ What is captured (all through the reference's own objects — `models/definition
                         tensor (set_nms(nms_thresh=-1): yolo3.py:1195-1206 returns it un-suppressed), the full-length
                         `box_nms` output (post_nms=-1; yolo3.py:1197-1200) and the (ids, scores, bboxes) of the
                         default call (0.45 / 400 / 100)
+  mxnet_infer_416_sparse.npz  the same capture with the objectness biases lowered by 7 (init.synthetic_params obj_bias=-7): a
+                        trained-like sparse candidate set (about 50 valid candidates) whose score gaps are mostly wide — where demanding EXACT kept
+                        rows is fair (with obj_bias 0 nearly all 212 940 candidates are valid and neighbouring scores of the top
+                        400 lie 1e-7 apart: any fp32 summation order other than mxnet's own swaps some of them)
+                        Every inference fixture also holds `top/index`, `top/scores`: mxnet's own pre-NMS top 1024 candidates
+                        per image in box_nms order, and `nms/first_rows_index`: the pre-NMS row each survivor came from —
+                        what tests/test_mxnet_goldens.py needs to tell a near-tie swap (score gap <= 1e-5) from an error
+  mxnet_ops.npz         the OPERATOR-LEVEL kit (tests/golden/mxnet_ops_kit.py): one tiny case per recalled semantic choice —
+                        box_nms on hand-built rows (thresholds met exactly, duplicate scores in both orders, a top-k cut
+                        through a tie, id -1 rows, force_suppress both ways), the same through hand-built LOGITS (the form
+                        the HIP path runs: vy_net_detect_heads), box_iou / BBoxBatchIOU on degenerate boxes, the reference's
+                        dynamic-target / merger / prefetch generators, YOLOV3Loss on a positive + ignored + negative anchor,
+                        one recorded step of the reference's `_conv2d` cell (running_var: biased or not), two SGD steps,
+                        imresize(interp=9) at a shrink, an enlarge and a mixed ratio.  tests/test_mxnet_ops.py replays it
   mxnet_train_96.npz    one recorded step on 2 frames of 96x96, 20 classes (train_yolov3.py:623-634): the four (B,)
                         losses (`YOLOV3Loss`, yolo3.py:994,1187), every parameter gradient, the BatchNorm running
                         statistics after the forward, and the parameters after `trainer.step(2)` with
@@ -57,6 +71,10 @@ def _load_by_path(name, path):
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     return mod
+
+
+KIT = _load_by_path("mxnet_ops_kit", os.path.join(HERE, "mxnet_ops_kit.py"))
+TOP = 1024   # pre-NMS candidates kept per image, in box_nms order (score descending, row ascending)
 
 
 def crc(a):
@@ -112,8 +130,9 @@ class MxnetBackend(object):
         self.mx, self.make = mx, yolo3_darknet53
         self.versions = "mxnet %s, gluoncv %s, numpy %s" % (mx.__version__, gluoncv.__version__, np.__version__)
         self.init = _load_by_path("vy_init", os.path.join(ROOT, "videoyolo_amd", "init.py"))
+        self.ops = KIT.MxnetOps(mx, yolo3_darknet53)
 
-    def build(self, classes, size):
+    def build(self, classes, size, obj_bias=0.0):
         mx = self.mx
         net = self.make(classes, pretrained_base=False, k=1)
         net.initialize()
@@ -121,14 +140,14 @@ class MxnetBackend(object):
         struct = net._collect_params_with_prefix()                           # structural names (save_parameters' keys)
         table = [(k, tuple(v.shape)) for k, v in struct.items()
                  if k.rsplit(".", 1)[1] in ("weight", "bias", "gamma", "beta", "running_mean", "running_var")]
-        params = self.init.synthetic_params(table, seed=233)
+        params = self.init.synthetic_params(table, seed=233, obj_bias=obj_bias)
         for k, v in params.items():
             struct[k].set_data(mx.nd.array(v))
         return net, struct, table, params
 
-    def infer(self, classes, x):
+    def infer(self, classes, x, obj_bias=0.0):
         mx = self.mx
-        net, struct, table, params = self.build(classes, x.shape[2])
+        net, struct, table, params = self.build(classes, x.shape[2], obj_bias)
         heads = {}
         for i in range(3):                                                   # stride 32, 16, 8 (yolo3.py:1013-1014)
             net.yolo_outputs[i].prediction.register_forward_hook(
@@ -185,23 +204,31 @@ class OracleBackend(object):
     """Plumbing check only (see the module docstring): the same captures from oracle/."""
     source = "oracle-selfcheck"
 
-    def __init__(self):
+    def __init__(self, perturb=0.0):
+        self.perturb = float(perturb)
         sys.path.insert(0, ROOT)
         from oracle import yolo3_oracle as O, yolo3_train_oracle as TO
         from videoyolo_amd import init
         self.O, self.TO, self.init = O, TO, init
         self.versions = "oracle/ of this repo, numpy %s" % np.__version__
+        self.ops = KIT.OracleOps()
 
-    def infer(self, classes, x):
+    def infer(self, classes, x, obj_bias=0.0):
         O = self.O
         C = len(classes)
         table = O.param_shapes(C)
-        params = self.init.synthetic_params(table, seed=233)
+        params = self.init.synthetic_params(table, seed=233, obj_bias=obj_bias)
         orc = O.OracleYolo3(C, params)
         heads = orc.raw_heads(x)
-        prenms = orc.detections(x)
+        if self.perturb:
+            # stand-in for "another fp32 summation order" (what mxnet's MKL-DNN convolution is to this repo's): the heads
+            # move by ~perturb relative, everything downstream is recomputed from them.  Shows what the first contact with
+            # real goldens looks like: near-tie swaps that tests/test_mxnet_goldens.py must classify, not fail on
+            rs = np.random.RandomState(99)
+            heads = [(h * (1.0 + self.perturb * rs.standard_normal(h.shape))).astype(np.float32) for h in heads]
+        prenms = orc.detections_from_heads(heads)
         full, _ = O.box_nms(prenms, 0.45, 0.01, 400)
-        ids, scores, bboxes, _ = orc(x)
+        ids, scores, bboxes, _ = orc.nms(prenms)
         return table, params, heads, prenms, full, (ids, scores, bboxes)
 
     def train(self, classes, x, gt_boxes, targets):
@@ -232,28 +259,86 @@ def meta(out, be, table, params, inputs):
         out["meta/crc_" + k] = np.array(crc(v), np.uint32)
 
 
-def capture_infer(be, outdir, size, seed):
+def top_candidates(prenms, valid_thresh=0.01, n=TOP):
+    """Per image the first n valid pre-NMS rows in box_nms order: (index (B, n) int64, scores (B, n) f32), -1 padded."""
+    b = prenms.shape[0]
+    idx = np.full((b, n), -1, np.int64)
+    sc = np.full((b, n), -1, np.float32)
+    for i in range(b):
+        s_ = prenms[i, :, 1]
+        v = np.nonzero(s_ > valid_thresh)[0]
+        o = v[np.lexsort((v, -s_[v].astype(np.float64)))][:n]
+        idx[i, :o.size], sc[i, :o.size] = o, s_[o]
+    return idx, sc
+
+
+def rows_to_index(prenms, rows):
+    """For every non-filler row of `rows` (B, k, 6) the index of the bit-identical row of `prenms` (B, N, 6); -1 for
+    filler, -2 where no row or more than one matches (identical candidates: the index is then not decidable from values)."""
+    out = np.full(rows.shape[:2], -1, np.int64)
+    for i in range(rows.shape[0]):
+        table = {}
+        cand = np.nonzero(prenms[i, :, 1] >= rows[i][rows[i, :, 0] >= 0][:, 1].min(initial=np.inf))[0]
+        for r in cand:
+            table.setdefault(prenms[i, r].tobytes(), []).append(int(r))
+        for j in range(rows.shape[1]):
+            if rows[i, j, 0] < 0:
+                continue
+            hit = table.get(np.ascontiguousarray(rows[i, j]).tobytes(), [])
+            out[i, j] = hit[0] if len(hit) == 1 else -2
+    return out
+
+
+def capture_infer(be, outdir, size, seed, obj_bias=0.0, tag=""):
     x = frames(1, size, seed)
-    table, params, heads, prenms, full, (ids, scores, bboxes) = be.infer(VOC, x)
+    table, params, heads, prenms, full, (ids, scores, bboxes) = be.infer(VOC, x, obj_bias)
     out = {}
     meta(out, be, table, params, {"x": x})
     out["in/size"], out["in/seed"] = np.array(size, np.int64), np.array(seed, np.int64)
+    out["in/obj_bias"] = np.array(obj_bias, np.float32)
     for i, h in enumerate(heads):
         if size <= 416:
             out["head%d" % i] = np.asarray(h, np.float32)
         else:
             pack_sampled(out, "head%d" % i, h, 1000 + i)
+    prenms = np.asarray(prenms, np.float32)
     pack_sampled(out, "prenms", prenms, 2000)
+    out["top/index"], out["top/scores"] = top_candidates(prenms)
     full = np.asarray(full, np.float32)
     n_valid = int((full[0, :, 0] >= 0).sum())
     out["nms/first_rows"] = full[:, :max(400, n_valid)].copy()              # survivors are compacted to the front
+    out["nms/first_rows_index"] = rows_to_index(prenms, out["nms/first_rows"])
     out["nms/rest_all_minus_one"] = np.array(bool((full[:, max(400, n_valid):] == -1).all()))
     out["nms/total_rows"] = np.array(full.shape[1], np.int64)
     out["ids"], out["scores"], out["bboxes"] = [np.asarray(t, np.float32) for t in (ids, scores, bboxes)]
-    path = os.path.join(outdir, "mxnet_infer_%d.npz" % size)
+    path = os.path.join(outdir, "mxnet_infer_%d%s.npz" % (size, tag))
     np.savez_compressed(path, **out)
-    print("wrote %s (%.1f KB): %d rows survive box_nms, %d returned" % (
-        path, os.path.getsize(path) / 1e3, n_valid, int((ids >= 0).sum())))
+    ts = out["top/scores"][0]
+    gaps = np.abs(np.diff(ts[:401][ts[:401] >= 0].astype(np.float64)))
+    print("wrote %s (%.1f KB): %d rows survive box_nms, %d returned; smallest gap among the top 401 pre-NMS scores %.3e" % (
+        path, os.path.getsize(path) / 1e3, n_valid, int((ids >= 0).sum()), gaps.min() if gaps.size else float("nan")))
+
+
+def capture_ops(be, outdir):
+    """The operator-level kit: every case of mxnet_ops_kit.all_cases() through the backend's operators."""
+    out = {"meta/source": np.array(be.source), "meta/versions": np.array(be.versions)}
+    names = []
+    for case in KIT.all_cases():
+        res = be.ops.run(case["op"], case["inputs"], case["params"])
+        pre = "ops/%s/" % case["name"]
+        out[pre + "op"] = np.array(case["op"])
+        out[pre + "decides"] = np.array(case["decides"])
+        for k, v in case["inputs"].items():
+            out[pre + "in/" + k] = np.asarray(v)
+        for k, v in case["params"].items():
+            out[pre + "par/" + k] = np.array(v, np.float64)
+        for k, v in res.items():
+            out[pre + "out/" + k] = np.asarray(v)
+        names.append(case["name"])
+    out["meta/cases"] = np.array(names)
+    path = os.path.join(outdir, "mxnet_ops.npz")
+    np.savez_compressed(path, **out)
+    print("wrote %s (%.1f KB): %d operator cases" % (path, os.path.getsize(path) / 1e3, len(names)))
 
 
 def capture_train(be, outdir, size=96, b=2, seed=235):
@@ -286,9 +371,12 @@ def main():
     ap.add_argument("--ref", default=os.environ.get("VIDEOYOLO_REF", "/root/reference"))
     ap.add_argument("--scratch", default="/tmp")
     ap.add_argument("--from-oracle", metavar="DIR", default=None)
+    ap.add_argument("--perturb", type=float, default=0.0,
+                    help="with --from-oracle: relative noise on the inference heads (1e-6 ~ another fp32 summation order) — "
+                         "rehearses the near-tie adjudication of tests/test_mxnet_goldens.py")
     args = ap.parse_args()
     if args.from_oracle:
-        be, outdir = OracleBackend(), args.from_oracle
+        be, outdir = OracleBackend(args.perturb), args.from_oracle
         os.makedirs(outdir, exist_ok=True)
         if os.path.realpath(outdir) == os.path.realpath(HERE):
             sys.exit("--from-oracle must not write into tests/golden/: those files would look like goldens")
@@ -299,7 +387,9 @@ def main():
             sys.exit("needs mxnet + gluoncv + the reference tree at --ref (%s): %s" % (args.ref, e))
         outdir = HERE
     print("capturing with", be.versions)
+    capture_ops(be, outdir)                 # the operator-level kit first: it is what localises a failure
     capture_infer(be, outdir, 416, 233)     # BASELINE configs[0]
+    capture_infer(be, outdir, 416, 233, obj_bias=-7.0, tag="_sparse")   # ~50 valid candidates, wide score gaps: exact rows are a fair demand
     capture_infer(be, outdir, 608, 234)
     capture_train(be, outdir)
     if not be.save_params(args.scratch):

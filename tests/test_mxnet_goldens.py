@@ -8,6 +8,18 @@ measured against) and `-m gpu` checks the HIP path through the C-ABI, both again
 Tolerances are north_star's: NMS ids / kept rows exact, scores, boxes and losses 1e-4 (boxes relative to the box
 extent: `exp(raw) * anchor` makes the error scale with the box), gradients 2e-3 of each tensor's max.
 
+"Kept rows exact" — with near-tie adjudication (`_check_kept_rows`).  mxnet's CPU convolution (MKL-DNN) sums in ITS order,
+this repo's oracle and kernels in theirs: the heads agree to ~1e-5, not bit for bit, and on the synthetic weights neighbouring
+scores among the top 400 candidates lie 1e-8 ... 1e-6 apart (the capture prints the smallest gap) — a ~1e-6 perturbation of
+the heads swaps such rows (the repo's own split-mode tests see exactly that, tests/test_gpu_split.py).  No fp32 evaluation
+that is not bit-identical to mxnet's can promise the order of two scores closer than its own error.  So:
+  * the fixture carries mxnet's OWN pre-NMS top-1024 scores / row indices and the pre-NMS row of every survivor;
+  * where every score gap around a row is > NEAR_TIE = 1e-5 (mxnet's numbers), the kept row must be EXACTLY mxnet's;
+  * a slot that differs is accepted only if both rows involved sit inside a near-tie group of mxnet's own sorted list (or
+    at the top-k cut) — each one is printed; anything else fails and names the rows and their gaps;
+  * `mxnet_infer_416_sparse` (objectness biases - 7: ~50 valid candidates) is the fixture where almost every gap is wide.
+The operator-level kit (tests/test_mxnet_ops.py) decides the comparators themselves on exactly representable inputs.
+
 VY_MXNET_GOLDEN_DIR points the tests at another directory — used once to exercise this file's plumbing with
 fixtures written by `make_mxnet_goldens.py --from-oracle` (source tag "oracle-selfcheck": they pin nothing).
 """
@@ -47,7 +59,7 @@ def _params(z, classes=20):
     assert sorted(names) == sorted(k for k, _ in table), "structural parameter names differ from the reference net's"
     for k, shp in table:
         assert shapes[k] == tuple(shp), (k, shapes[k], shp)
-    params = init.synthetic_params(table, seed=233)
+    params = init.synthetic_params(table, seed=233, obj_bias=float(z["in/obj_bias"]) if "in/obj_bias" in z else 0.0)
     crcs = dict(zip(names, z["meta/param_crc"]))
     for k, v in params.items():
         assert (zlib.crc32(np.ascontiguousarray(v).tobytes()) & 0xFFFFFFFF) == int(crcs[k]), \
@@ -77,7 +89,69 @@ def _sampled(z, key, arr, atol=None, rel_to_max=None):
     assert abs(f.sum() - float(z[key + "/sum"])) <= tol * n, key           # nothing outside the sample drifted either
 
 
-def _check_inference(z, heads, prenms, nms_rows, ids, scores, bboxes):
+def _boxes_close(got, want, boxes, what):
+    """|got - want| <= 1e-4 * max(1, w, h) of the box the coordinate belongs to (`boxes` (n, 4) corner rows, one per
+    element or per row of got): `exp(raw) * anchor` makes the error of a coordinate relative to the box EXTENT — a 1000-px
+    box whose corner sits at x = 3 cannot promise 1e-4 of 3 (the bar tests/test_oracle_vs_torch.py uses between two
+    independently ordered fp32 evaluations)."""
+    boxes = np.asarray(boxes, np.float64).reshape(-1, 4)
+    ext = np.maximum(1.0, np.maximum(np.abs(boxes[:, 2] - boxes[:, 0]), np.abs(boxes[:, 3] - boxes[:, 1])))
+    got, want = np.asarray(got, np.float64), np.asarray(want, np.float64)
+    if got.ndim == 2:
+        ext = ext[:, None]
+    fin = np.isfinite(want)
+    assert np.array_equal(np.isfinite(got), fin), what
+    err = np.abs(got - want) / np.broadcast_to(ext, got.shape)
+    assert not fin.any() or err[fin].max() <= 1e-4, "%s: worst coordinate error %.3e of its box extent (bar 1e-4)" % (what, err[fin].max())
+
+
+NEAR_TIE = 1e-5   # score gap (in mxnet's own pre-NMS scores) below which the order of two candidates is not demanded
+
+
+def _near_tie_rows(z, b, topk=400):
+    """Pre-NMS rows of image b whose score lies within NEAR_TIE of a neighbour in mxnet's own sorted candidate list (and
+    the rows around the top-k cut when the cut falls inside such a group): {row: score}."""
+    idx, sc = z["top/index"][b], z["top/scores"][b].astype(np.float64)
+    n = int((idx >= 0).sum())
+    near = {}
+    for j in range(n):
+        lo = j > 0 and abs(sc[j] - sc[j - 1]) <= NEAR_TIE
+        hi = j + 1 < n and abs(sc[j] - sc[j + 1]) <= NEAR_TIE
+        if lo or hi:
+            near[int(idx[j])] = float(sc[j])
+    score_of = {int(idx[j]): float(sc[j]) for j in range(n)}
+    return near, score_of
+
+
+def _check_kept_rows(z, got_index, label, capsys=None, topk=400):
+    """got_index (B, k): the pre-NMS row of each kept row of this implementation, in output order, -1 filler; compared
+    with mxnet's survivors (`nms/first_rows_index`) over the first k slots.  Returns the accepted near-tie exceptions."""
+    want_all = z["nms/first_rows_index"]
+    report = []
+    for b in range(want_all.shape[0]):
+        k = min(got_index.shape[1], want_all.shape[1])
+        want, got = want_all[b, :k].astype(np.int64), np.asarray(got_index[b, :k], np.int64)
+        if np.array_equal(want, got):
+            continue
+        near, score_of = _near_tie_rows(z, b, topk)
+        for j in np.nonzero(want != got)[0]:
+            w, g = int(want[j]), int(got[j])
+            if w == -2:
+                continue   # mxnet kept one of several bit-identical candidates: its index is not decidable from values
+            ok = (w in near or w < 0) and (g in near or g < 0)
+            gap = abs(score_of.get(w, float("nan")) - score_of.get(g, float("nan")))
+            assert ok, ("%s: image %d slot %d: mxnet keeps pre-NMS row %d (score %r), this implementation row %d (score %r) — "
+                        "neither a near-tie (gap %.3e > %.0e in mxnet's own scores) nor explained by one: a real difference"
+                        % (label, b, int(j), w, score_of.get(w), g, score_of.get(g), gap, NEAR_TIE))
+            report.append((b, int(j), g, w, gap))
+        assert len(report) <= max(8, k // 10), "%s: %d slots differ — too many to be near-ties" % (label, len(report))
+    if report and capsys is not None:
+        with capsys.disabled():
+            print("\n[%s] near-tie exceptions (image, slot, row here, mxnet's row, mxnet score gap): %s" % (label, report))
+    return report
+
+
+def _check_inference(z, heads, prenms, nms_rows, nms_index, ids, scores, bboxes, keep, label, capsys=None):
     for i in range(3):
         if "head%d" % i in z:
             np.testing.assert_allclose(heads[i], z["head%d" % i], rtol=0, atol=1e-4)
@@ -93,49 +167,101 @@ def _check_inference(z, heads, prenms, nms_rows, ids, scores, bboxes):
         assert np.array_equal(got[col == 0], want[col == 0])
         np.testing.assert_allclose(got[col == 1], want[col == 1], rtol=0, atol=1e-4)
         box = col >= 2
-        np.testing.assert_allclose(got[box], want[box], rtol=1e-4, atol=1e-4)
+        rows = prenms.reshape(-1, 6)[idx[box] // 6]
+        _boxes_close(got[box], want[box], rows[:, 2:], "pre-NMS boxes")
     want = z["nms/first_rows"]
     assert bool(z["nms/rest_all_minus_one"])
+    exc = []
+    if nms_index is not None:
+        exc = _check_kept_rows(z, nms_index, label + " (all survivors)", capsys)
+    if keep is not None:
+        exc += _check_kept_rows(z, keep, label + " (returned rows)", capsys)
+    # values: slot by slot where the kept row is mxnet's; a near-tie exception's slot holds its partner's values, which differ
+    # in score by <= NEAR_TIE but may be ANOTHER class / box — those slots are compared as a set below
+    skip = {(b, j) for b, j, _, _, _ in exc}
+
+    def slots(k):
+        m = np.ones((want.shape[0], k), bool)
+        for b, j in skip:
+            if j < k:
+                m[b, j] = False
+        return m
+
     if nms_rows is not None:
         k = want.shape[1]
-        assert np.array_equal(nms_rows[:, :k, 0], want[:, :, 0]), "class ids of the box_nms survivors differ"
-        np.testing.assert_allclose(nms_rows[:, :k, 1], want[:, :, 1], rtol=0, atol=1e-4)
-        np.testing.assert_allclose(nms_rows[:, :k, 2:], want[:, :, 2:], rtol=1e-4, atol=1e-4)
+        m = slots(k)
+        assert np.array_equal(nms_rows[:, :k, 0][m], want[:, :, 0][m]), "class ids of the box_nms survivors differ"
+        np.testing.assert_allclose(nms_rows[:, :k, 1], want[:, :, 1], rtol=0, atol=1e-4)   # (scores: every slot, ties included)
+        _boxes_close(nms_rows[:, :k, 2:][m], want[:, :, 2:][m], nms_rows[:, :k, 2:][m], "boxes of the box_nms survivors")
         assert (nms_rows[:, k:] == -1).all()
-    assert np.array_equal(ids, z["ids"]), "ids of the 100 returned rows differ from mxnet's"
+    m = slots(ids.shape[1])[..., None]
+    assert np.array_equal(ids[m], z["ids"][m]), "ids of the returned rows differ from mxnet's"
     np.testing.assert_allclose(scores, z["scores"], rtol=0, atol=1e-4)
-    np.testing.assert_allclose(bboxes, z["bboxes"], rtol=1e-4, atol=1e-4)
+    _boxes_close(bboxes[m[..., 0]], z["bboxes"][m[..., 0]], bboxes[m[..., 0]], "returned boxes")
 
 
-@pytest.mark.parametrize("size", [416, 608])
-def test_oracle_inference_matches_mxnet(size):
-    """BASELINE configs[0] (and one 608 x 608 frame): the CPU checker against the reference's own outputs."""
+FIXTURES = [("416", 0.0), ("416_sparse", -7.0), ("608", 0.0)]
+
+
+def test_near_tie_adjudication_accepts_swaps_inside_a_tie_and_nothing_else():
+    """The adjudication itself, on a hand-made fixture (no mxnet needed): mxnet's sorted candidates have scores
+    0.9, 0.8, 0.8 - 3e-7, 0.5, 0.4 (rows 10, 11, 12, 13, 14): rows 11 / 12 form the only near-tie group."""
+    z = {"top/index": np.array([[10, 11, 12, 13, 14, -1]], np.int64),
+         "top/scores": np.array([[0.9, 0.8, 0.8 - 3e-7, 0.5, 0.4, -1]], np.float32),
+         "nms/first_rows_index": np.array([[10, 11, 12, 13, 14, -1]], np.int64)}
+    assert _check_kept_rows(z, np.array([[10, 11, 12, 13, 14, -1]]), "same") == []
+    exc = _check_kept_rows(z, np.array([[10, 12, 11, 13, 14, -1]]), "swap inside the tie")
+    assert [(e[1], e[2], e[3]) for e in exc] == [(1, 12, 11), (2, 11, 12)] and all(e[4] < NEAR_TIE for e in exc)
+    with pytest.raises(AssertionError, match="a real difference"):
+        _check_kept_rows(z, np.array([[10, 11, 12, 14, 13, -1]]), "swap of two scores 0.1 apart")
+    with pytest.raises(AssertionError, match="a real difference"):
+        _check_kept_rows(z, np.array([[10, 11, 12, 13, -1, -1]]), "a row mxnet keeps is missing")
+    with pytest.raises(AssertionError, match="a real difference"):
+        _check_kept_rows(z, np.array([[10, 11, 12, 13, 14, 99]]), "a row mxnet does not keep")
+    # one of two tied rows suppressed by the other (same class, overlapping): the survivor may be either
+    z["nms/first_rows_index"] = np.array([[10, 11, 13, 14, -1, -1]], np.int64)
+    assert len(_check_kept_rows(z, np.array([[10, 12, 13, 14, -1, -1]]), "the other row of the tie survives")) == 1
+
+
+def _params_for(z):
+    """The capture's parameters (synthetic, seed 233, with the fixture's objectness bias), CRC-checked against the capture."""
+    return _params(z)
+
+
+@pytest.mark.parametrize("tag,obj_bias", FIXTURES, ids=[t for t, _ in FIXTURES])
+def test_oracle_inference_matches_mxnet(tag, obj_bias, capsys):
+    """BASELINE configs[0] (and its sparse variant, and one 608 x 608 frame): the CPU checker against the reference's own outputs."""
     from oracle import yolo3_oracle as O
-    z = _load("mxnet_infer_%d.npz" % size)
-    params, x = _params(z), _input(z)
+    z = _load("mxnet_infer_%s.npz" % tag)
+    assert float(z["in/obj_bias"]) == obj_bias
+    params, x = _params_for(z), _input(z)
     orc = O.OracleYolo3(20, params)
     heads = orc.raw_heads(x)
     prenms = orc.detections(x)
-    full, _ = O.box_nms(prenms, 0.45, 0.01, 400)
-    ids, scores, bboxes, _ = orc(x)
+    full, full_idx = O.box_nms(prenms, 0.45, 0.01, 400)
+    ids, scores, bboxes, keep = orc(x)
     assert full.shape[1] == int(z["nms/total_rows"])
-    _check_inference(z, heads, prenms, full, ids, scores, bboxes)
+    k = z["nms/first_rows"].shape[1]
+    _check_inference(z, heads, prenms, full, full_idx[:, :k], ids, scores, bboxes, keep, "oracle %s" % tag, capsys)
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("size", [416, 608])
-def test_hip_inference_matches_mxnet(size):
+@pytest.mark.parametrize("tag,obj_bias", FIXTURES, ids=[t for t, _ in FIXTURES])
+def test_hip_inference_matches_mxnet(tag, obj_bias, capsys):
     import videoyolo_amd as vy
-    z = _load("mxnet_infer_%d.npz" % size)
-    params, x = _params(z), _input(z)
+    z = _load("mxnet_infer_%s.npz" % tag)
+    params, x = _params_for(z), _input(z)
     net = vy.yolo3_darknet53(G.VOC, pretrained_base=False)
     net.set_parameters(params)
     net.collect_params().reset_ctx("cuda:0")
-    ids, scores, bboxes = [t.cpu().numpy() for t in net(x)]
+    ids, scores, bboxes, keep = [t.cpu().numpy() for t in net(x, return_index=True)]
     heads = [net.read_head(i).cpu().numpy() for i in range(3)]
+    net.set_nms(0.45, 400, -1)                                             # every row box_nms looked at (nms_topk of them)
+    surv = net(x, return_index=True)[3].cpu().numpy()
     net.set_nms(-1, 400, -1)                                               # the detection tensor itself (yolo3.py:1197)
     prenms = np.concatenate([t.cpu().numpy() for t in net(x)], -1)
-    _check_inference(z, heads, prenms, None, ids, scores, bboxes)
+    k = min(surv.shape[1], z["nms/first_rows"].shape[1])
+    _check_inference(z, heads, prenms, None, surv[:, :k], ids, scores, bboxes, keep, "HIP %s" % tag, capsys)
 
 
 def _check_training(z, losses, grad_of, running_of, updated_of):

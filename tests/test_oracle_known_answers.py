@@ -203,3 +203,65 @@ def test_param_table_invariants():
     assert "stages.0.0.0.weight" in names and "stages.2.4.body.1.1.running_var" in names
     assert "yolo_blocks.2.tip.0.weight" in names and "transitions.1.1.gamma" in names
     assert "yolo_outputs.0.prediction.bias" in names
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The dependency's PUBLISHED docstring examples (recalled from the operator documentation of mxnet.ndarray.contrib.box_nms /
+# box_iou; tests/golden/mxnet_ops_kit.py KNOWN_ANSWERS).  The only numbers in this repository that come from mxnet's own
+# published text rather than from recollection of its behaviour: they pin "sort by score, suppress above overlap_thresh
+# regardless of class under force_suppress, survivors first, -1 filler" and "corner IoU without +1".  The HIP path cannot
+# take arbitrary rows (its NMS is fused behind the decode: boxes come from anchors); it shares include/vy_math.h's
+# vy_box_iou and the comparator semantics with the oracle, and tests/test_mxnet_ops.py's `heads_*` cases run the same
+# decisions through vy_net_detect_heads.
+# ---------------------------------------------------------------------------------------------------------------------
+def _kit():
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("mxnet_ops_kit", os.path.join(os.path.dirname(os.path.abspath(__file__)),
+                                                                                "golden", "mxnet_ops_kit.py"))
+    kit = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(kit)
+    return kit
+
+
+def test_published_box_nms_docstring_example():
+    kit = _kit()
+    ka = kit.KNOWN_ANSWERS["box_nms_doc"]
+    out = kit.OracleOps().run("box_nms", dict(data=ka["data"]), ka["params"])["out"]
+    assert np.array_equal(out, ka["out"]), out
+
+
+def test_published_box_iou_docstring_example():
+    kit = _kit()
+    ka = kit.KNOWN_ANSWERS["box_iou_doc"]
+    ops = kit.OracleOps()
+    out = ops.run("box_iou", dict(lhs=ka["lhs"], rhs=ka["rhs"]), {})["out"]
+    np.testing.assert_allclose(out, ka["out"], rtol=0, atol=ka["atol"])
+    assert abs(float(out[0, 0]) - 1.0 / 7.0) < 1e-7            # 0.0625 / (0.25 + 0.25 - 0.0625)
+    # the same pair through the two other IoU routes of the path: BBoxBatchIOU's formula (ref_ops.c vyo_batch_iou) and
+    # box_nms's comparator (vy_math.h vy_box_iou): a row pair whose IoU is 1/7 is suppressed at 0.14 and kept at 0.15
+    b = ops.run("bbox_batch_iou", dict(a=ka["lhs"][None], b=ka["rhs"][None]), {})["out"]
+    np.testing.assert_allclose(b[0], out, rtol=0, atol=1e-7)
+    rows = np.array([[[0, 0.9] + ka["lhs"][0].tolist(), [0, 0.8] + ka["rhs"][0].tolist()]], np.float32)
+    for thr, kept in ((0.14, 1), (0.15, 2)):
+        o = ops.run("box_nms", dict(data=rows), dict(overlap_thresh=thr, valid_thresh=0.0, topk=-1, force_suppress=0))["out"]
+        assert int((o[0, :, 0] >= 0).sum()) == kept
+
+
+def test_operator_kit_covers_every_recalled_choice():
+    """Every kit case runs through the oracle (so `--from-oracle` can always rehearse the capture) and the list covers the
+    [UPSTREAM-RECALLED] choices the verdicts enumerated."""
+    kit = _kit()
+    ops = kit.OracleOps()
+    cases = kit.all_cases()
+    for c in cases:
+        out = ops.run(c["op"], c["inputs"], c["params"])
+        assert out and all(np.asarray(v).size for v in out.values()), c["name"]
+    have = {c["op"] for c in cases}
+    assert have >= {"box_nms", "detect_heads", "box_iou", "bbox_batch_iou", "dynamic_targets", "target_merger", "prefetch_targets",
+                    "yolov3_loss", "conv_bn_leaky", "sgd", "imresize"}
+    names = " ".join(c["name"] for c in cases)
+    for needle in ("valid_thresh", "overlap_thresh", "duplicate_scores_ab", "duplicate_scores_ba", "topk_cuts_through_tie",
+                   "background_id", "force_suppress_0", "force_suppress_1", "iou_at_thresh", "label_smooth_1", "no_wd",
+                   "shrink", "enlarge", "mixed"):
+        assert needle in names, needle

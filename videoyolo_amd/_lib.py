@@ -62,6 +62,7 @@ SIGNATURES = {
     "vy_net_streamk_state": (ctypes.c_int, [_vp, ctypes.POINTER(_i32), ctypes.POINTER(_sz), ctypes.POINTER(_i32)]),
     "vy_net_num_anchors": (_i32, [_vp]),
     "vy_net_forward_infer": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "vy_net_detect_heads": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "vy_net_read_head": (ctypes.c_int, [_vp, _i32, _vp, _vp]),
     "vy_net_read_activation": (ctypes.c_int, [_vp, ctypes.c_char_p, _vp, ctypes.POINTER(_i32),
                                               ctypes.POINTER(_i32), ctypes.POINTER(_i32), _vp]),

@@ -144,6 +144,8 @@ hipError_t vy_launch_bn_fold(float* params, const FoldDesc* descs_dev, int n_lay
 // plane view -> dense NCHW copy (parity taps)
 hipError_t vy_launch_plane_to_nchw(const float* plane, int B, int H, int W, int cs, int co, int C,
                                    float* dst, hipStream_t s);
+hipError_t vy_launch_nchw_to_plane(const float* src, int B, int H, int W, int cs, int co, int C, float* plane,
+                                   hipStream_t s);
 
 // ---- detection tail -------------------------------------------------------------------------
 #define VY_NMS_MAX_TOPK 1024

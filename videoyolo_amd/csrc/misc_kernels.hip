@@ -218,6 +218,30 @@ __global__ void plane_to_nchw_kernel(const float* plane, int B, int H, int W, in
   }
 }
 
+// dense NCHW -> plane view (vy_net_detect_heads: caller-supplied prediction tensors into the head planes)
+__global__ void nchw_to_plane_kernel(const float* src, int B, int H, int W, int cs, int co, int C, float* plane) {
+  const long long n = (long long)B * C * H * W;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int x = (int)(i % W);
+    long long t = i / W;
+    const int y = (int)(t % H);
+    t /= H;
+    const int c = (int)(t % C);
+    const int b = (int)(t / C);
+    plane[((long long)(b * (H + 2) + y + 1) * (W + 2) + x + 1) * cs + co + c] = src[i];
+  }
+}
+
+hipError_t vy_launch_nchw_to_plane(const float* src, int B, int H, int W, int cs, int co, int C, float* plane,
+                                   hipStream_t s) {
+  const long long n = (long long)B * C * H * W;
+  long long blocks = (n + 255) / 256;
+  if (blocks > 65536) blocks = 65536;
+  hipLaunchKernelGGL(nchw_to_plane_kernel, dim3((unsigned)blocks), dim3(256), 0, s, src, B, H, W, cs, co, C, plane);
+  return hipGetLastError();
+}
+
 hipError_t vy_launch_plane_to_nchw(const float* plane, int B, int H, int W, int cs, int co, int C,
                                    float* dst, hipStream_t s) {
   const long long n = (long long)B * C * H * W;

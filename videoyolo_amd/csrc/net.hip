@@ -236,6 +236,25 @@ int vy_net_read_head(vy_net* net, int32_t i, float* dst_dev, void* stream) {
   return 0;
 }
 
+int vy_net_detect_heads(vy_net* net, const float* head0, const float* head1, const float* head2, float* ids, float* scores,
+                        float* bboxes, int32_t* keep_idx, void* stream) {
+  if (!net || !head0 || !head1 || !head2 || !ids || !scores || !bboxes) return fail(VY_ERR_INVALID, "null argument");
+  if (int rc = net->check_ready()) return rc;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const float* src[3] = {head0, head1, head2};
+  for (int i = 0; i < 3; ++i) {
+    const PlaneT& p = net->planes[net->head_plane[i]];
+    HIP_TRY(vy_launch_nchw_to_plane(src[i], net->B, p.H, p.W, p.C, 0, 3 * (5 + net->num_class),
+                                    net->plane_ptr(net->head_plane[i]), s));
+  }
+  const DetArgs d = net->det_args();
+  if (net->nms_thresh > 0.f && net->nms_thresh < 1.f)  // yolo3.py:1197
+    HIP_TRY(vy_launch_detect(d, net->dev_ws + net->det_scratch_off, ids, scores, bboxes, keep_idx, s));
+  else
+    HIP_TRY(vy_launch_raw_detections(d, ids, scores, bboxes, keep_idx, s));
+  return 0;
+}
+
 int vy_net_read_activation(vy_net* net, const char* name, float* dst_dev, int32_t* c, int32_t* h, int32_t* w,
                            void* stream) {
   if (!net || !name) return fail(VY_ERR_INVALID, "bad argument");

@@ -762,6 +762,37 @@ class YOLOV3(object):
             return ids, scores, bboxes, keep
         return ids, scores, bboxes
 
+    def detect_heads(self, heads, size, return_index=False):
+        """The detection tail alone (``vy_net_detect_heads``): ``heads`` = the three prediction-conv outputs
+        (B, 3*(5+C), H_i, W_i) for strides 32, 16, 8 of a ``size`` = (height, width) input — what
+        ``net.yolo_outputs[i](pred)`` (yolo3.py:132-199), the concat (:1195), ``box_nms`` and the slice (:1197-1206)
+        make of them.  Honours ``set_nms`` like a forward."""
+        torch = _torch()
+        if self._device is None:
+            raise RuntimeError("parameters are not on a device: call net.collect_params().reset_ctx(ctx)")
+        h, w = (size, size) if isinstance(size, int) else size
+        hs = [self._dev(t) for t in heads]
+        if len(hs) != 3:
+            raise ValueError("three head tensors (strides 32, 16, 8)")
+        b = int(hs[0].shape[0])
+        c = 3 * (5 + len(self._classes))
+        for t, div in zip(hs, (32, 16, 8)):
+            want = (b, c, -(-h // div), -(-w // div))
+            if tuple(t.shape) != want:
+                raise ValueError("head of stride %d: shape %s, expected %s" % (div, tuple(t.shape), want))
+        with torch.cuda.device(self._device):
+            self._ensure_plan(b, h, w)
+            rows = self._out_rows()
+            ids = torch.empty((b, rows, 1), dtype=torch.float32, device=self._device)
+            scores = torch.empty((b, rows, 1), dtype=torch.float32, device=self._device)
+            bboxes = torch.empty((b, rows, 4), dtype=torch.float32, device=self._device)
+            keep = torch.empty((b, rows), dtype=torch.int32, device=self._device) if return_index else None
+            _lib.check(self._lib.vy_net_detect_heads(
+                self._h, *[ctypes.c_void_p(t.data_ptr()) for t in hs], ctypes.c_void_p(ids.data_ptr()),
+                ctypes.c_void_p(scores.data_ptr()), ctypes.c_void_p(bboxes.data_ptr()),
+                ctypes.c_void_p(keep.data_ptr()) if keep is not None else None, self._stream()))
+        return (ids, scores, bboxes, keep) if return_index else (ids, scores, bboxes)
+
     def detect_two_streams(self, x, return_index=False):
         """Frames are independent, so a large batch is run as two half-batches on two HIP streams (a twin
         vy_net that shares the parameter buffer, with its own workspace).  Every layer's launch covers a
