@@ -169,6 +169,54 @@ SPLIT_DTYPE = "f32 via bf16x3 (6 products), f32 acc"
 _JSON_FD = None
 
 
+class LegWatchdog(object):
+    """A wall-clock budget per leg.  A leg of a multi-rank run that stops making progress (a collective whose peer never
+    arrives, a fabric that is mis-set) would otherwise hold the whole run until the process group's timeout — and take the
+    already measured headline with it, because the contract's ONE line is printed at the end.  Every rank arms the same
+    budget at the start of every leg; when it runs out, rank 0 prints the line with everything measured so far, the current
+    leg as {"timeout": true} and the legs not reached as absent, and every rank leaves (exit code 0 when the headline
+    `value` is in the line, 4 otherwise).  Nothing is killed by pattern and nothing execs: the process ends itself."""
+
+    def __init__(self, rank, budget_s, result):
+        import threading
+        self.rank, self.budget, self.result = rank, float(budget_s), result
+        self.leg, self.deadline = None, None
+        self.lock = threading.Lock()
+        if self.budget > 0:
+            threading.Thread(target=self._run, daemon=True).start()
+
+    def arm(self, leg, scale=1.0):
+        with self.lock:
+            self.leg, self.deadline = leg, time.time() + self.budget * scale
+
+    def disarm(self):
+        with self.lock:
+            self.leg, self.deadline = None, None
+
+    def _run(self):
+        while True:
+            time.sleep(0.5)
+            with self.lock:
+                leg, dl = self.leg, self.deadline
+            if dl is not None and time.time() > dl:
+                self.fire(leg)
+
+    def fire(self, leg):
+        sys.stderr.write("bench.py: leg %r exceeded its wall-clock budget of %.0f s on rank %d: reporting what was measured\n"
+                         % (leg, self.budget, self.rank))
+        if self.rank == 0:
+            for _ in range(5):
+                try:
+                    out = dict(self.result)
+                    out[leg if leg != "headline" else "headline_leg"] = {"timeout": True, "budget_s": self.budget}
+                    out["aborted_after_timeout_of"] = leg
+                    _emit(out)
+                    break
+                except RuntimeError:   # the main thread was adding to the dict: take another copy
+                    time.sleep(0.05)
+        os._exit(0 if "value" in self.result else 4)
+
+
 def _emit(result):
     """the one line of the contract, on the process's REAL stdout (main() points fd 1 at stderr: library chatter)"""
     line = (json.dumps(result) + "\n").encode()
@@ -631,6 +679,14 @@ def main():
     ap.add_argument("--vid-size", type=int, default=608, help="also_vid608: network input size (tests use small ones)")
     ap.add_argument("--train-steps", type=int, default=20, help="timed steps of each training leg (20: a 0.6 s window; 10 was short enough for one host hiccup to cost 10 %)")
     ap.add_argument("--train-size", type=int, default=416)
+    ap.add_argument("--no-preflight", action="store_true",
+                    help="N > 1: skip the collective pre-flight (5 barriers + 5 all-reduces of the 246.5 MB gradient buffer: sum "
+                         "checked, bus bandwidth against the xGMI expectation; a failure exits 3 with a one-line reason)")
+    ap.add_argument("--preflight-min-busbw", type=float, default=None,
+                    help="fail the pre-flight below this all-reduce bus bandwidth (GB/s); default: report only")
+    ap.add_argument("--leg-budget-s", type=float, default=600.0,
+                    help="wall-clock budget per leg: a leg that exceeds it is reported as {\"timeout\": true} and the line is "
+                         "printed with everything measured before it (0: no watchdog)")
     ap.add_argument("--no-multiscale-leg", action="store_true", help="skip also_train_multiscale (the reference's default training mode)")
     ap.add_argument("--multiscale-interval", type=int, default=10, help="steps per size (train_yolov3.py:270 interval=10)")
     ap.add_argument("--multiscale-sizes", default=",".join(str(v) for v in MULTISCALE_SIZES), help="tests use small ones")
@@ -702,9 +758,28 @@ def main():
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
 
-    if args.mode == "train":
-        return bench_train(args, vy, dev, dist, rank, world, traffic, traffic_note)
+    # What a multi-rank number ran on, stated by the run itself (every rank contributes its device's identity), and a
+    # pre-flight of the collectives before any leg: a mis-set fabric ends the run here, in seconds, with one line.
+    collective = None
+    if dist is not None:
+        from videoyolo_amd import parallel
+        collective = parallel.describe_group(dev)
+        if not args.no_preflight:
+            pf = parallel.preflight(dev, min_busbw_GBps=args.preflight_min_busbw if world > 1 else None)
+            collective["preflight"] = pf
+            if not pf["ok"]:
+                if rank == 0:
+                    sys.stderr.write("bench.py: collective pre-flight failed: %s\n" % pf["reason"])
+                    _emit({"error": "collective pre-flight failed: " + pf["reason"], "n_gpus": world, "collective": collective})
+                dist.destroy_process_group()
+                sys.exit(3)
 
+    if args.mode == "train":
+        return bench_train(args, vy, dev, dist, rank, world, traffic, traffic_note, collective)
+
+    result = {}
+    dog = LegWatchdog(rank, args.leg_budget_s, result)
+    dog.arm("headline")
     classes = ["c%d" % i for i in range(args.classes)]
     net = vy.yolo3_darknet53(classes, pretrained_base=False)
     net.initialize(init="synthetic", seed=233, obj_bias=args.obj_bias)
@@ -726,7 +801,7 @@ def main():
     frames = args.batch * world * args.steps
     fps = frames / dt
 
-    result = {
+    result.update({
         "metric": "frames/sec, yolo3_darknet53 inference %dx%d" % (args.size, args.size),
         "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
@@ -737,8 +812,16 @@ def main():
                    "per_gpu_batch": args.batch, "global_batch": args.batch * world, "size": args.size,
                    "classes": args.classes, "parallelism": "frame-scatter x%d" % world,
                    "kept_detections_rank0": int((out[0] >= 0).sum().item())},
-    }
+    })
+    if collective is not None:
+        # (second gather: now every rank's net has bound its workspace, so the stream-K placement probe has a verdict)
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, {"rank": rank, "streamk_enabled": net.streamk_enabled()})
+        for d, e in zip(collective["devices"], per_rank):
+            d["streamk_enabled"] = e["streamk_enabled"]
+        result["collective"] = collective
 
+    dog.arm("roofline")
     if rank == 0 and not args.no_roofline:
         # per-launch HIP-event timing of extra passes (same stream the kernels run on)
         med, agg = launch_table(net, x)
@@ -797,6 +880,7 @@ def main():
             result["roofline"]["decode_nms"] = {
                 "ms": tail[1], "algorithmic_GBps": tail[3] / (tail[1] * 1e-3) / 1e9, "hbm_peak_GBps": HBM_PEAK_GBS}
 
+    dog.arm("latency_batch1")
     if rank == 0 and world == 1 and not args.no_latency:
         result["latency_batch1"] = batch1_latency(net, x[:1].contiguous(), torch, args.size, args.classes)
 
@@ -818,6 +902,7 @@ def main():
                               "frac_of_fp32_mfma_peak": None if gflop4 is None else fps4 * gflop4 / 1e3 / FP32_MFMA_PEAK_TFLOPS}
         del x4
 
+    dog.arm("also_infer%d_split" % args.size)
     if args.conv_mode == "exact" and not args.no_split_leg:
         # The same step in the opt-in split-fp32 conv mode, on every rank, timed the same way.  NOT the headline.
         net.set_conv_mode("split_bf16x3")
@@ -893,6 +978,7 @@ def main():
         result["also_infer%d_split" % args.size] = leg
         net.set_conv_mode("exact")
 
+    dog.arm("cpu_baseline")
     if rank == 0 and world == 1 and args.cpu_frames > 0:
         # CPU baseline: the oracle (a port of the same algorithm; NOT the reference's MXNet path,
         # which cannot be installed here) on a bounded sample of the same workload
@@ -928,11 +1014,13 @@ def main():
         hw = lambda t: tuple(int(v) for v in t.lower().split("x"))  # noqa: E731
         del x, out
         torch.cuda.empty_cache()
+        dog.arm("also_hostfed%d" % args.size)
         result["also_hostfed%d" % args.size] = dict(
             host_fed_leg(vy, dev, dist, rank, world, args.size, args.batch, args.classes, args.steps, args.warmup, hw(args.src_hw),
                          conv_mode=args.conv_mode, obj_bias=args.obj_bias, resident_fps=fps),
             workload="the headline step fed from the host: decoded %s uint8 frames in pinned host memory instead of a resident "
                      "fp32 batch (detect_yolo3.py:209-233, transforms.py:316-350)" % args.src_hw)
+        dog.arm("also_vid%d" % args.vid_size)
         result["also_vid%d" % args.vid_size] = dict(
             host_fed_leg(vy, dev, dist, rank, world, args.vid_size, args.vid_batch, 30, args.steps, args.warmup, hw(args.vid_src_hw),
                          conv_mode=args.conv_mode),
@@ -946,6 +1034,7 @@ def main():
         # The inference net's buffers are released first (each leg builds its own net).
         del net, x, out
         torch.cuda.empty_cache()
+        dog.arm("also_train416")
         leg = train_leg(vy, dev, dist, rank, world, args.train_size, args.train_batch, args.classes,
                         args.train_steps, args.warmup, syncbn=False, overlap=True, allreduce_alone=True)
         leg["workload"] = ("BASELINE.json configs[2]: training step, VOC-shape synthetic (%d cls, 8 gt/img), %dx%d, "
@@ -963,6 +1052,7 @@ def main():
             leg["traffic_note"] = train_traffic_note
         result["also_train416"] = leg
         if not args.no_multiscale_leg:
+            dog.arm("also_train_multiscale", scale=2.0)   # (100 steps at ten sizes)
             ms = multiscale_leg(vy, dev, dist, rank, world, args.train_batch, args.classes, args.multiscale_interval, args.warmup,
                                 sizes=tuple(int(v) for v in args.multiscale_sizes.split(",")))
             ms["workload"] = ("the reference's DEFAULT training mode (train_yolov3.py:258-271, RandomTransformDataLoader interval=%d): "
@@ -974,6 +1064,7 @@ def main():
         if not args.no_split_leg:
             # the same training step in conv mode split_bf16x3_train (forward, data and weight gradients on the bf16 matrix
             # core; NOT the parity path): separately reported, like also_infer608_split
+            dog.arm("also_train416_split")
             sleg = train_leg(vy, dev, dist, rank, world, args.train_size, args.train_batch, args.classes,
                              args.train_steps, args.warmup, syncbn=False, overlap=True, allreduce_alone=False,
                              conv_mode="split_bf16x3_train")
@@ -982,6 +1073,7 @@ def main():
             sleg["workload"] = leg["workload"] + "; net.set_conv_mode('split_bf16x3_train')"
             result["also_train416_split"] = sleg   # named like also_train416 (the leg carries its size)
         if world > 1 or forced:
+            dog.arm("also_syncbn608")
             leg = train_leg(vy, dev, dist, rank, world, args.syncbn_size, args.syncbn_batch, args.classes,
                             args.train_steps, args.warmup, syncbn=True, overlap=True, allreduce_alone=False)
             leg["workload"] = ("BASELINE.json configs[4]: SyncBN training step, %dx%d, per-GPU batch %d, net built with "
@@ -989,6 +1081,7 @@ def main():
                                "over %d ranks" % (args.syncbn_size, args.syncbn_size, args.syncbn_batch, world, world))
             result["also_syncbn608"] = leg
 
+    dog.disarm()
     if rank == 0:
         _emit(result)
     if dist is not None:
@@ -996,8 +1089,10 @@ def main():
         dist.destroy_process_group()
 
 
-def bench_train(args, vy, dev, dist, rank, world, traffic=None, traffic_note=None):
+def bench_train(args, vy, dev, dist, rank, world, traffic=None, traffic_note=None, collective=None):
     """--mode train: BASELINE configs[2]/[4] as the headline line (see train_leg)."""
+    dog = LegWatchdog(rank, args.leg_budget_s, {})
+    dog.arm("headline")
     leg = train_leg(vy, dev, dist, rank, world, args.size, args.batch, args.classes, args.steps, args.warmup,
                     syncbn=args.syncbn, overlap=not args.no_overlap, split=not args.no_roofline,
                     allreduce_alone=not args.no_roofline, conv_mode=args.conv_mode)
@@ -1039,6 +1134,9 @@ def bench_train(args, vy, dev, dist, rank, world, traffic=None, traffic_note=Non
                 "top_kernels_MB_per_step": {k[:56]: round(v["hbm_bytes"] * v["launches"] / 3.0 / 1e6, 1) for k, v in top}}
         else:
             result["roofline"]["traffic_note"] = traffic_note
+    if collective is not None:
+        result["collective"] = collective
+    dog.disarm()
     if rank == 0:
         _emit(result)
     if dist is not None:

@@ -85,6 +85,11 @@ def main():
     for n in RUNNING:                                   # after ONE recorded forward
         out["A_running/" + n] = net.collect_params()[n].data()
     out["A_buckets"] = np.array(trainer._overlap.last_launched, np.int64)
+    # the host-side mirror of the library's bucket bookkeeping (parallel.grad_bucket_table: what the world-4 / world-8 CPU
+    # tests check for coverage) is what the library actually reported during this backward
+    from videoyolo_amd import parallel as _par
+    assert [tuple(b) for b in trainer._overlap.last_launched] == [(o, c) for _, o, c in _par.grad_bucket_table(net)], \
+        (trainer._overlap.last_launched, _par.grad_bucket_table(net))
     trainer.disable_overlap()
     fwd_bwd(net)
     trainer.allreduce_grads()

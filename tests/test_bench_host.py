@@ -123,3 +123,40 @@ def test_ipc_mode_is_set_before_torch_whatever_the_launcher():
     p = subprocess.run([sys.executable, "-c", "import sys, os; sys.path.insert(0, %r); import bench; print(os.environ['HSA_ENABLE_IPC_MODE_LEGACY'])" % ROOT],
                        env=env, capture_output=True, text=True, timeout=300)
     assert p.stdout.strip() == "1"
+
+
+_DOG = textwrap.dedent('''\
+    import sys, time
+    sys.path.insert(0, %r)
+    import bench
+    result = {"value": 123.0, "also_416": {"frames_per_s": 1.0}} if sys.argv[1] == "with_headline" else {}
+    dog = bench.LegWatchdog(0, 1.0, result)
+    dog.arm("also_train416")
+    dog.disarm()
+    time.sleep(1.6)               # a disarmed budget never fires
+    dog.arm("also_syncbn608")
+    time.sleep(30)                # "a collective whose peer never arrives"
+    print("NOT REACHED")
+    ''')
+
+
+def test_leg_watchdog_prints_the_line_and_ends_the_run(tmp_path):
+    """A leg that exceeds its wall-clock budget: rank 0 prints the contract line with everything measured before it and the
+    leg as {"timeout": true}; exit code 0 when the headline value is in the line, 4 when nothing was measured."""
+    import json
+    import subprocess
+    import time
+    script = tmp_path / "dog.py"
+    script.write_text(_DOG % ROOT)
+    for mode, rc in (("with_headline", 0), ("nothing", 4)):
+        t0 = time.time()
+        p = subprocess.run([sys.executable, str(script), mode], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=60)
+        assert p.returncode == rc and time.time() - t0 < 25, (p.returncode, p.stderr.decode()[-500:])
+        out = p.stdout.decode()
+        assert "NOT REACHED" not in out
+        line = json.loads(out.strip().splitlines()[-1])
+        assert line["also_syncbn608"] == {"timeout": True, "budget_s": 1.0} and line["aborted_after_timeout_of"] == "also_syncbn608"
+        assert "also_train416" not in line            # it was disarmed in time
+        if mode == "with_headline":
+            assert line["value"] == 123.0 and line["also_416"] == {"frames_per_s": 1.0}
+        assert "exceeded its wall-clock budget" in p.stderr.decode()

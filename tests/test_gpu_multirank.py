@@ -184,7 +184,8 @@ def test_bench_starts_its_own_ranks(extra):
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--share-gpu",
            "--size", "96", "--batch", "2", "--steps", "2", "--warmup", "1", "--cpu-frames", "0",
            "--train-size", "64", "--train-batch", "2", "--syncbn-size", "96", "--syncbn-batch", "2",
-           "--train-steps", "2", "--no-split-leg", "--src-hw", "60x80", "--vid-src-hw", "48x64", "--vid-size", "96", "--vid-batch", "3"] + extra   # (the split legs at 2 ranks: test_bench_under_torch_distributed_run)
+           "--train-steps", "2", "--no-split-leg", "--src-hw", "60x80", "--vid-src-hw", "48x64", "--vid-size", "96", "--vid-batch", "3",
+           "--multiscale-sizes", "64,96", "--multiscale-interval", "2"] + extra   # (the split legs at 2 ranks: test_bench_under_torch_distributed_run)
     p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
     assert p.returncode == 0, p.stderr.decode()[-2000:]
     lines = p.stdout.decode().splitlines()
@@ -192,6 +193,16 @@ def test_bench_starts_its_own_ranks(extra):
     r = json.loads(lines[0])
     assert r["n_gpus"] == 2 and r["config"]["global_batch"] == 4 and r["value"] > 0
     assert r["scaling"] == "weak" and r["steps"] == 2
+    # the line says what it ran on: two ranks of a gloo group that SHARE one device — reported, not inferred
+    col = r["collective"]
+    assert col["backend"] == "gloo" and col["world"] == 2 and col["ranks_in_order"] and col["distinct_devices"] == 1
+    assert [d["rank"] for d in col["devices"]] == [0, 1] and col["devices"][0]["cus"] > 0 and col["ipc_mode"] == "dmabuf"
+    assert col["preflight"]["ok"] and col["preflight"]["allreduce_bytes"] > 240e6 and col["preflight"]["world"] == 2
+    if not extra:
+        assert all(d["streamk_enabled"] in (True, False) for d in col["devices"])
+        ms = r["also_train_multiscale"]
+        assert ms["n_gpus"] == 2 and sorted(ms["sizes_in_order"]) == [64, 96] and ms["steps"] == 4 and ms["frames_per_s"] > 0
+        assert set(ms["per_size"]) == {"64", "96"} and all(v["replan_ms"] > 0 for v in ms["per_size"].values())
     if not extra:
         t = r["also_train416"]
         for k in ("frames_per_s", "ms_per_step", "forward_ms", "backward_ms", "allreduce_exposed_ms", "sgd_ms",
@@ -225,7 +236,8 @@ def test_bench_under_torch_distributed_run():
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--share-gpu",
            "--size", "96", "--batch", "2", "--steps", "2", "--warmup", "1", "--cpu-frames", "0",
            "--train-size", "64", "--train-batch", "2", "--syncbn-size", "96", "--syncbn-batch", "2", "--train-steps", "2",
-           "--src-hw", "60x80", "--vid-src-hw", "48x64", "--vid-size", "96", "--vid-batch", "2"]
+           "--src-hw", "60x80", "--vid-src-hw", "48x64", "--vid-size", "96", "--vid-batch", "2",
+           "--multiscale-sizes", "64,96", "--multiscale-interval", "2"]
     p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
     assert p.returncode == 0, p.stderr.decode()[-2000:]
     lines = p.stdout.decode().splitlines()
@@ -242,12 +254,14 @@ def test_default_bench_line_has_the_training_leg_on_one_gpu():
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--size", "96", "--batch", "2", "--steps", "2", "--warmup", "1",
            "--cpu-frames", "1", "--train-size", "64", "--train-batch", "2", "--train-steps", "2",
-           "--src-hw", "60x80", "--vid-src-hw", "48x64", "--vid-size", "96", "--vid-batch", "2"]
+           "--src-hw", "60x80", "--vid-src-hw", "48x64", "--vid-size", "96", "--vid-batch", "2",
+           "--multiscale-sizes", "64,96", "--multiscale-interval", "2"]
     p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1200)
     assert p.returncode == 0, p.stderr.decode()[-2000:]
     r = json.loads([l for l in p.stdout.decode().splitlines() if l.startswith("{")][0])
     t = r["also_train416"]
-    assert t["n_gpus"] == 1 and t["allreduce"].startswith("none") and "also_syncbn608" not in r
+    assert t["n_gpus"] == 1 and t["allreduce"].startswith("none") and "also_syncbn608" not in r and "collective" not in r
+    assert r["also_train_multiscale"]["steps"] == 4 and r["also_train_multiscale"]["replan_share"] < 1.0
     assert t["forward_ms"] > 0 and t["backward_ms"] > 0 and t["allreduce_exposed_ms"] < 0.5
     if os.path.exists("/opt/rocm/bin/rocprofv3"):
         assert r["roofline"]["traffic"] and t["traffic"] and t["traffic"] > 0, (r["roofline"].get("traffic_note"), t.get("traffic_note"))

@@ -41,10 +41,19 @@ def test_bench_runs_its_training_legs_over_rccl_on_one_gpu():
                         "--force-collectives", "--size", "96", "--batch", "2", "--steps", "2", "--warmup", "1",
                         "--train-size", "96", "--train-batch", "2", "--train-steps", "2", "--syncbn-size", "96",
                         "--syncbn-batch", "2", "--cpu-frames", "0", "--no-pmc", "--no-latency", "--no-split-leg",
-                        "--src-hw", "60x80", "--vid-src-hw", "48x64", "--vid-size", "96", "--vid-batch", "2"],
+                        "--src-hw", "60x80", "--vid-src-hw", "48x64", "--vid-size", "96", "--vid-batch", "2",
+                        "--multiscale-sizes", "64,96", "--multiscale-interval", "2"],
                        env=env, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stderr[-3000:]
     r = json.loads(p.stdout.strip().splitlines()[-1])
+    # the line proves what it ran on: RCCL, its version, the device's PCI address, the pre-flight's 246.5 MB all-reduce
+    col = r["collective"]
+    assert col["backend"] == "nccl" and col["world"] == 1 and col["rccl_version"] and col["distinct_devices"] == 1
+    d0 = col["devices"][0]
+    assert d0["rank"] == 0 and d0["cus"] > 0 and d0["hbm_bytes"] > 100e9 and d0["streamk_enabled"] in (True, False)
+    assert d0["pci_bus_id"] or d0["uuid"], d0
+    assert col["preflight"]["ok"] and col["preflight"]["backend"] == "nccl" and col["preflight"]["allreduce_ms"] > 0
+    assert r["also_train_multiscale"]["backend"] == "nccl"
     leg = r["also_train416"]
     assert leg["backend"] == "nccl" and leg["allreduce"].startswith("bucketed")
     assert leg["allreduce_alone_ms"] > 0 and leg["allreduce_bytes"] > 240e6

@@ -850,6 +850,15 @@ class YOLOV3(object):
             return ids, scores, bboxes, keep
         return ids, scores, bboxes
 
+    def streamk_enabled(self):
+        """Did the bind-time placement probe (8 XCDs, workgroups dealt round-robin: csrc/conv_igemm.hip
+        vy_sk_verify_topology) enable chain-preserving stream-K on this net's device?  None before a workspace is bound."""
+        if self._plan is None:
+            return None
+        en = ctypes.c_int32(0)
+        _lib.check(self._lib.vy_net_streamk_state(self._h, ctypes.byref(en), None, None))
+        return bool(en.value)
+
     def read_head(self, i):
         """Prediction-conv output of head i (stride 32,16,8) of the last forward, NCHW."""
         torch = _torch()

@@ -136,20 +136,27 @@ def host_group():
     return _host_group
 
 
-def make_host_group():
-    """Collective: every rank must call it (idempotent)."""
+def _new_gloo_group():
+    """The gloo group beside an RCCL default group (its own function: the world-4 / world-8 tests make it fail on one rank)."""
+    dist = _dist()
+    # single node (the launch contract): gloo over loopback — the container's hostname may not resolve
+    if os.environ.get("MASTER_ADDR", "127.0.0.1") in ("127.0.0.1", "localhost"):
+        os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+    return dist.new_group(backend="gloo", timeout=group_timeout())
+
+
+def make_host_group(side_group=None):
+    """Collective: every rank must call it (idempotent).  side_group: None = a gloo default group IS the host group and
+    only an RCCL default group gets a gloo group beside it; True forces the side-group path on any backend (tests)."""
     global _host_group
     if not collectives_active() or _host_group is not None:
         return _host_group
     dist = _dist()
-    if dist.get_backend() == "gloo":
+    if dist.get_backend() == "gloo" and not side_group:
         _host_group = dist.group.WORLD
     else:
         try:
-            # single node (the launch contract): gloo over loopback — the container's hostname may not resolve
-            if os.environ.get("MASTER_ADDR", "127.0.0.1") in ("127.0.0.1", "localhost"):
-                os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
-            grp = dist.new_group(backend="gloo", timeout=group_timeout())
+            grp = _new_gloo_group()
         except Exception as e:  # no usable host interface for gloo on THIS rank
             import warnings
             warnings.warn("no gloo side group on rank %d (%s)" % (rank(), e))
@@ -159,14 +166,14 @@ def make_host_group():
         # "I have the group" on the DEFAULT group; if any rank failed, every rank uses the fallback.
         import torch
         ok = torch.tensor([1 if grp is not None else 0], dtype=torch.int32,
-                          device=torch.device("cuda", torch.cuda.current_device()))
+                          device="cpu" if dist.get_backend() == "gloo" else torch.device("cuda", torch.cuda.current_device()))
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         if int(ok.item()) == 1:
             _host_group = grp
         else:
             import warnings
             warnings.warn("gloo side group unavailable on at least one rank: control-plane agreement falls back to "
-                          "one-element RCCL all-reduces with a host read-back per recorded forward")
+                          "one-element all-reduces on the default group (RCCL: with a host read-back per recorded forward)")
             _host_group = False
     return _host_group
 
@@ -220,6 +227,134 @@ def sync_replicas_if_any_dirty(net, src=0):
     if any_rank(not net._replicas_synced, net._device):
         return sync_replicas(net, src)
     return False
+
+
+XGMI_LINK_GBPS_PER_DIRECTION = 76.8   # 7 point-to-point links per GPU, ~153.6 GB/s each counting both directions
+
+
+def device_identity(device=None, extra=None):
+    """What THIS rank runs on, as plain data: rank, local rank, host, pid, device ordinal, name, CUs, HBM bytes, PCI bus id,
+    the environment that decides how ranks see each other's memory.  `extra`: caller's per-rank facts (e.g. the stream-K
+    placement probe's verdict of its net)."""
+    import socket
+    import torch
+    d = {"rank": rank(), "local_rank": int(os.environ.get("LOCAL_RANK", "0")), "host": socket.gethostname(), "pid": os.getpid(),
+         "ipc_mode_legacy": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"),
+         "visible_devices": os.environ.get("HIP_VISIBLE_DEVICES", os.environ.get("ROCR_VISIBLE_DEVICES"))}
+    if device is not None and torch.cuda.is_available() and str(device).startswith("cuda"):
+        dev = torch.device(device)
+        pr = torch.cuda.get_device_properties(dev)
+        bus = None
+        if all(hasattr(pr, k) for k in ("pci_domain_id", "pci_bus_id", "pci_device_id")):
+            bus = "%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+        d.update(device=dev.index if dev.index is not None else torch.cuda.current_device(), name=pr.name,
+                 cus=int(pr.multi_processor_count), hbm_bytes=int(pr.total_memory), pci_bus_id=bus,
+                 gcn_arch=getattr(pr, "gcnArchName", None), uuid=str(getattr(pr, "uuid", "")) or None)
+    else:
+        d.update(device=str(device) if device is not None else "cpu")
+    if extra:
+        d.update(extra)
+    return d
+
+
+def describe_group(device=None, extra=None):
+    """Collective (every rank calls it): `{backend, world, rccl_version, ipc_mode, devices: [per-rank identity], ...}` —
+    the proof of WHAT a multi-rank number ran on, gathered with all_gather_object.  `distinct_devices` counts the different
+    (host, PCI bus id) pairs: N ranks on fewer than N devices is reported, not inferred.  Without a process group: the
+    one-rank description."""
+    import torch
+    me = device_identity(device, extra)
+    out = {"backend": None, "world": 1, "rccl_version": None, "ipc_mode": "dmabuf" if me["ipc_mode_legacy"] == "0" else
+           "legacy (HSA_ENABLE_IPC_MODE_LEGACY=%s)" % me["ipc_mode_legacy"], "devices": [me]}
+    if is_initialized():
+        dist = _dist()
+        out["backend"], out["world"] = dist.get_backend(), dist.get_world_size()
+        if out["backend"] == "nccl":
+            try:
+                out["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+            except Exception as e:  # pragma: no cover
+                out["rccl_version"] = "unknown (%s)" % e
+        got = [None] * out["world"]
+        dist.all_gather_object(got, me)
+        out["devices"] = got
+    keys = {(d.get("host"), d.get("pci_bus_id") or d.get("uuid") or d.get("device")) for d in out["devices"]}
+    out["distinct_devices"] = len(keys)
+    out["ranks_in_order"] = [d.get("rank") for d in out["devices"]] == list(range(out["world"]))
+    return out
+
+
+def allreduce_expectation(nbytes, world):
+    """What an all-reduce of nbytes over `world` fully connected GPUs can reach on xGMI: one ring uses
+    one link per neighbour (bus bandwidth <= 76.8 GB/s); reduce-scatter + all-gather over all world - 1 links at once
+    <= (world - 1) x 76.8."""
+    if world < 2:
+        return None
+    f = 2.0 * (world - 1) / world * nbytes
+    all_links = (world - 1) * XGMI_LINK_GBPS_PER_DIRECTION
+    return {"all_links_rs_ag_busbw_GBps": all_links, "single_ring_busbw_GBps": XGMI_LINK_GBPS_PER_DIRECTION,
+            "ms_at_all_links": f / (all_links * 1e9) * 1e3, "ms_at_single_ring": f / (XGMI_LINK_GBPS_PER_DIRECTION * 1e9) * 1e3}
+
+
+def preflight(device, nbytes=246_504_196, iters=5, min_busbw_GBps=None, max_barrier_ms=None, budget_s=5.0):
+    """Collective pre-flight of a multi-rank run (every rank calls it; <= a few seconds): `iters` barriers (latency) and
+    `iters` all-reduces of an nbytes fp32 buffer (the flat gradient buffer's size: 246.5 MB) — correctness of the sum, time,
+    bus bandwidth against the xGMI expectation.  Returns a dict with "ok" and, when not ok, a one-line "reason" that is THE
+    SAME on every rank (the verdict is computed from all-reduced numbers), so that all ranks leave together instead of
+    some of them entering the legs.  A mis-set fabric shows up here in seconds, not as a hang in the first training step:
+    the group's timeout bounds every collective (VY_DIST_TIMEOUT_S)."""
+    import time
+    import torch
+    dist = _dist()
+    w, r = world_size(), rank()
+    on_gpu = str(device).startswith("cuda")
+    sync = (lambda: torch.cuda.synchronize(device)) if on_gpu else (lambda: None)
+    t_start = time.perf_counter()
+    n = max(1, int(nbytes) // 4)
+    buf = torch.empty(n, dtype=torch.float32, device=device)
+    bar = []
+    for _ in range(iters):
+        sync()
+        t0 = time.perf_counter()
+        dist.barrier()
+        sync()
+        bar.append(1e3 * (time.perf_counter() - t0))
+    ts, good = [], True
+    for i in range(iters):
+        buf.fill_(float(r + 1))
+        sync()
+        dist.barrier()
+        t0 = time.perf_counter()
+        dist.all_reduce(buf)
+        sync()
+        ts.append(1e3 * (time.perf_counter() - t0))
+        want = w * (w + 1) / 2.0
+        good = good and bool((buf[:: max(1, n // 4096)] == want).all().item()) and float(buf[-1].item()) == want
+    # the verdict from numbers every rank shares: max over ranks of the median times, min of the correctness flags
+    v = torch.tensor([sorted(ts)[len(ts) // 2], sorted(bar)[len(bar) // 2], 0.0 if good else 1.0, time.perf_counter() - t_start],
+                     dtype=torch.float64, device=device if on_gpu else "cpu")
+    dist.all_reduce(v, op=dist.ReduceOp.MAX)
+    ar_ms, bar_ms, bad, took = (float(t) for t in v.tolist())
+    busbw = 2.0 * (w - 1) / w * (n * 4) / (ar_ms * 1e-3) / 1e9 if w > 1 else None
+    out = {"ok": True, "world": w, "backend": dist.get_backend(), "allreduce_bytes": n * 4, "allreduce_ms": ar_ms,
+           "allreduce_busbw_GBps": busbw, "barrier_ms": bar_ms, "iters": iters, "seconds": took,
+           "expectation": allreduce_expectation(n * 4, w) if on_gpu else None}
+    if out["expectation"]:
+        out["frac_of_all_links"] = busbw / out["expectation"]["all_links_rs_ag_busbw_GBps"]
+        out["frac_of_single_ring"] = busbw / out["expectation"]["single_ring_busbw_GBps"]
+    reasons = []
+    if bad:
+        reasons.append("all-reduce(sum) of rank + 1 over %d ranks did not give %g on every rank" % (w, w * (w + 1) / 2.0))
+    if min_busbw_GBps is not None and busbw is not None and busbw < min_busbw_GBps:
+        reasons.append("all-reduce bus bandwidth %.1f GB/s < floor %.1f GB/s (xGMI single ring would give %.1f): the ranks do not "
+                       "talk over the fabric" % (busbw, min_busbw_GBps, XGMI_LINK_GBPS_PER_DIRECTION))
+    if max_barrier_ms is not None and bar_ms > max_barrier_ms:
+        reasons.append("barrier latency %.2f ms > %.2f ms" % (bar_ms, max_barrier_ms))
+    if took > budget_s:
+        out["over_budget"] = True   # reported, not fatal: the first collective of a communicator also builds its rings
+    if reasons:
+        out.update(ok=False, reason="; ".join(reasons))
+    del buf
+    return out
 
 
 def gather_detections(ids, scores, bboxes, total=None):
@@ -291,6 +426,28 @@ class SyncBatchNormHook(object):
     def begin_step(self):
         """Called by the recorded forward: the call log covers one step (it is instrumentation, not state)."""
         self.calls = []
+
+
+def grad_bucket_table(net):
+    """The gradient buckets of a backward pass, in the order the library reports them (csrc/train.hip: heads -> stages.2 ->
+    stages.1 -> stages.0, the order backward finishes them): [(name, element offset, element count)] over the flat gradient
+    buffer — host-side mirror of the library's bookkeeping, from the parameter table alone (no device needed).  Ranges are
+    the contiguous extents of each group's TRAINABLE tensors (weight, gamma, beta, bias), ends rounded up to 64 elements
+    (the 256-byte alignment of the parameter table).  Every rank derives the same table: the all-reduces of bucket i pair up
+    across ranks by construction."""
+    groups = [("heads", lambda n: not n.startswith("stages.")), ("stages.2", lambda n: n.startswith("stages.2.")),
+              ("stages.1", lambda n: n.startswith("stages.1.")), ("stages.0", lambda n: n.startswith("stages.0."))]
+    out = []
+    for gname, pred in groups:
+        lo, hi = None, 0
+        for p in net.collect_params().values():
+            if not pred(p.name) or p.name.rsplit(".", 1)[1] in ("running_mean", "running_var"):
+                continue
+            lo = p.offset if lo is None else min(lo, p.offset)
+            hi = max(hi, p.offset + ((p.size + 63) & ~63))
+        if lo is not None and hi > lo:
+            out.append((gname, int(lo), int(hi - lo)))
+    return out
 
 
 class GradBucketOverlap(object):
