@@ -588,53 +588,27 @@ def host_fed_leg(vy, dev, dist, rank, world, size, batch, classes, steps, warmup
     return leg
 
 
-def torch_cpu_baseline(params, x, classes):
-    """torch-CPU forward of the same 75-conv graph (conv + eval BatchNorm + LeakyReLU, residuals, upsample + concat,
-    prediction convs): an independent CPU datapoint for BASELINE.md 4 — NOT the reference's MXNet path, and not the
-    checker (oracle/).  Decode + NMS (< 0.5 % of the work) are not included.  Returns seconds for len(x) frames."""
-    import torch
-    import torch.nn.functional as F
-    p = {k: torch.from_numpy(v) for k, v in params.items()}
-
-    def cell(t, pre, k, s):
-        t = F.conv2d(t, p[pre + ".0.weight"], None, s, k // 2)
-        t = F.batch_norm(t, p[pre + ".1.running_mean"], p[pre + ".1.running_var"], p[pre + ".1.gamma"],
-                         p[pre + ".1.beta"], False, 0.9, 1e-5)
-        return F.leaky_relu(t, 0.1)
-
-    def forward(t):
-        routes, idx = [], 0
-        stage_of = [(0, 15), (15, 24), (24, 29)]
-        feats = [("c", 1)]
-        for n in (1, 2, 8, 8, 4):
-            feats += [("c", 2)] + [("b", 0)] * n
-        for si, (lo, hi) in enumerate(stage_of):
-            for j, f in enumerate(feats[lo:hi]):
-                pre = "stages.%d.%d" % (si, j)
-                if f[0] == "c":
-                    t = cell(t, pre, 3, f[1])
-                else:
-                    t = t + cell(cell(t, pre + ".body.0", 1, 1), pre + ".body.1", 3, 1)
-            routes.append(t)
-        outs, t = [], routes[2]
-        for i in range(3):
-            for j in range(5):
-                t = cell(t, "yolo_blocks.%d.body.%d" % (i, j), 1 if j % 2 == 0 else 3, 1)
-            tip = cell(t, "yolo_blocks.%d.tip" % i, 3, 1)
-            outs.append(F.conv2d(tip, p["yolo_outputs.%d.prediction.weight" % i], p["yolo_outputs.%d.prediction.bias" % i]))
-            if i == 2:
-                break
-            t = F.interpolate(cell(t, "transitions.%d" % i, 1, 1), scale_factor=2, mode="nearest")
-            r = routes[1 - i]
-            t = torch.cat([t[:, :, :r.shape[2], :r.shape[3]], r], 1)
-        return outs
-
-    xt = torch.from_numpy(x)
-    with torch.no_grad():
-        forward(xt[:1])  # warm-up (thread pool, primitive caches)
-        t0 = time.perf_counter()
-        forward(xt)
-        return time.perf_counter() - t0
+def torch_cpu_child(params, frames, classes, gflop_per_frame):
+    """The torch-CPU datapoint in a CHILD process (tools/cpu_torch_baseline.py): one thread per physical core of this
+    process's cpuset, bound to cores, a warm-up pass at the same shape — settings an OpenMP runtime only takes at start-up.
+    The child never touches a GPU.  Returns its JSON (or a note why it could not run): never fails the line."""
+    import subprocess
+    import tempfile
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    try:
+        import cpu_torch_baseline as ctb
+        with tempfile.TemporaryDirectory(prefix="vy_cpu_", dir="/tmp") as d:
+            np.savez(os.path.join(d, "p.npz"), **params)
+            np.save(os.path.join(d, "x.npy"), frames)
+            p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "cpu_torch_baseline.py"), os.path.join(d, "p.npz"),
+                                os.path.join(d, "x.npy"), "--classes", str(classes), "--gflop-per-frame", str(gflop_per_frame)],
+                               env=ctb.child_env(), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+        if p.returncode != 0:
+            return {"value": None, "note": "child failed (rc %d): %s" % (p.returncode, p.stderr.decode()[-300:])}
+        return json.loads(p.stdout.decode().strip().splitlines()[-1])
+    except Exception as e:
+        return {"value": None, "note": "%s: %s" % (type(e).__name__, e)}
 
 
 def main():
@@ -648,8 +622,8 @@ def main():
     ap.add_argument("--obj-bias", type=float, default=0.0,
                     help="added to the objectness biases (-5: trained-like sparse candidates)")
     ap.add_argument("--cpu-frames", type=int, default=4, help="frames of the CPU-oracle sample (0: skip)")
-    ap.add_argument("--cpu-torch-frames", type=int, default=32,
-                    help="frames of the torch-CPU datapoint (one batch: the host's cores need a batch this size to be busy)")
+    ap.add_argument("--cpu-torch-frames", type=int, default=8,
+                    help="frames of the torch-CPU datapoint, as one batch (SURVEY 8d's recipe: batch 8, threads = physical cores)")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--mode", choices=["infer", "train"], default="infer",
                     help="infer: BASELINE configs[1] headline + the training legs (default); train: configs[2] as the "
@@ -994,18 +968,17 @@ def main():
             "kind": "port",
             "sample": "%d frames of the same %dx%d batch through oracle/ (C + OpenMP conv, numpy graph, "
                       "C NMS); MXNet itself is not installable here" % (args.cpu_frames, args.size, args.size)}
-        try:
-            nt = max(1, min(args.cpu_torch_frames, args.batch))
-            tdt = torch_cpu_baseline(params, x[:nt].cpu().numpy(), args.classes)
-            result["cpu_baseline_torch"] = {
-                "value": nt / tdt, "unit": "frames/s", "cores": int(torch.get_num_threads()),
-                "host": {"cpu_count": os.cpu_count(), "affinity": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None,
-                         "fp32_tflops": nt / tdt * FWD_GFLOP_PER_FRAME.get((args.size, args.classes), 0.0) / 1e3},
-                "kind": "independent", "sample": "%d frames of the same batch, as ONE batch, through torch-CPU conv2d / batch_norm / "
-                "leaky_relu of the same 75-conv graph (no decode / NMS); an independent CPU datapoint, NOT MXNet and not the checker"
-                % nt}
-        except Exception as e:  # a second datapoint: never fail the line for it
-            result["cpu_baseline_torch"] = {"value": None, "note": "%s: %s" % (type(e).__name__, e)}
+        try:  # what the host offers (the thread count above is what the OpenMP runtime of the port actually used)
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import cpu_torch_baseline as ctb
+            result["cpu_baseline"]["host"] = ctb.host_facts()
+            gf = FWD_GFLOP_PER_FRAME.get((args.size, args.classes))
+            if gf:
+                result["cpu_baseline"]["fp32_tflops"] = args.cpu_frames / cdt * gf / 1e3
+        except Exception:
+            pass
+        result["cpu_baseline_torch"] = torch_cpu_child(params, x[:max(1, min(args.cpu_torch_frames, args.batch))].cpu().numpy(),
+                                                       args.classes, FWD_GFLOP_PER_FRAME.get((args.size, args.classes), 0.0))
         del orc, params
 
     if not args.no_host_legs:

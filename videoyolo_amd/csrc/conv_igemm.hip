@@ -51,6 +51,10 @@ struct SkArgs {
   float* partials;
   unsigned* flags;
   int tiles;
+  // > 0: split-K launch (grid = tiles x ksplit): block (tile, chunk c) runs k-steps [c T / S, (c + 1) T / S) as its OWN
+  // chain from +0; chunks 0 .. S - 2 leave their sums in a slab, the block of chunk S - 1 adds them IN CHUNK ORDER to its
+  // own — ((P0 + P1) + P2) + P3 — and runs the epilogue.  0: the stream-K schedule.
+  int ksplit;
 };
 
 // One tile of the implicit GEMM, k-steps [kb, ke): from zero or (SK) from the previous block's partial sums, to the
@@ -58,7 +62,7 @@ struct SkArgs {
 template <int BM, int BN, int WM, int WN, bool DGRAD, int NS, bool SK, typename Args>
 __device__ __forceinline__ void conv_tile(Args& a, const int tiles_n, const SkArgs& sk, unsigned char* smem,
                                           const int vblk, const int v, const int kb, const int ke,
-                                          const bool load_partial, const bool store_partial) {
+                                          const bool load_partial, const bool store_partial, const int ks_reduce = 0) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
   constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
@@ -394,6 +398,46 @@ __device__ __forceinline__ void conv_tile(Args& a, const int tiles_n, const SkAr
   }
 
   VY_TRACE(2)
+  if constexpr (SK) {
+    if (ks_reduce > 0) {
+      // split-K: this block ran the LAST chunk.  The blocks of chunks 0 .. ks_reduce - 1 (slab / flag index c * tiles + v)
+      // raise their flags without waiting for anything; add their sums in chunk order, then this block's own
+      if (tid == 0) {
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        for (int c = 0; c < ks_reduce; ++c)
+          while (__hip_atomic_load(sk.flags + (c * sk.tiles + v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+            __builtin_amdgcn_s_sleep(2);
+            if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) __builtin_trap();
+          }
+      }
+      __syncthreads();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const unsigned off = (unsigned)((((i * TN + j) * 4 + q) * NT + tid) * 16);
+            f32x4 t4 = {0.f, 0.f, 0.f, 0.f};
+            for (int c = 0; c < ks_reduce; ++c) {
+              const __amdgpu_buffer_rsrc_t slab = __builtin_amdgcn_make_buffer_rsrc(
+                  sk.partials + (size_t)(c * sk.tiles + v) * (BM * BN), 0, BM * BN * 4, 0x00020000);
+              const f32x4 p4 = buf_load_f32x4_sc1(slab, off);
+              if (c == 0) t4 = p4;
+              else
+#pragma unroll
+                for (int e = 0; e < 4; ++e) t4[e] = t4[e] + p4[e];
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[i][j][q * 4 + e] = t4[e] + acc[i][j][q * 4 + e];
+          }
+      __syncthreads();
+      if (tid == 0)
+        for (int c = 0; c < ks_reduce; ++c)
+          __hip_atomic_store(sk.flags + (c * sk.tiles + v), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
   if (SK && load_partial && tid == 0)  // every thread passed a k-loop barrier after loading its partial sums
     __hip_atomic_store(sk.flags + (vblk - 1), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (SK && store_partial) {
@@ -610,6 +654,17 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_kernel(const ConvA
     // (32-bit arithmetic made scalar again by hand: tiles x blocks < 2^31 is checked by the launcher; a 64-bit division
     // is expanded into vector code with control flow and its results then count as per-lane values)
     auto sdiv = [](unsigned n, unsigned d) { return (int)__builtin_amdgcn_readfirstlane((int)(n / d)); };
+    if (sk.ksplit > 0) {
+      typedef const __attribute__((address_space(4))) ConvArgs KArgs;
+      KArgs* ap = (KArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+      const int chunk = sdiv((unsigned)vblk, (unsigned)sk.tiles), tile = vblk - chunk * sk.tiles;
+      const int kb = sdiv((unsigned)(chunk * T_all), (unsigned)sk.ksplit), ke = sdiv((unsigned)((chunk + 1) * T_all), (unsigned)sk.ksplit);
+      const bool last = chunk == sk.ksplit - 1;
+      // (the slab / flag of chunk c's block is index c * tiles + tile == its vblk)
+      conv_tile<BM, BN, WM, WN, DGRAD, NS, SK, KArgs>(*ap, tiles_n, sk, smem, vblk, tile, kb, ke, false, !last,
+                                                       last ? sk.ksplit - 1 : 0);
+      return;
+    }
     const SkSchedule sch = sk_schedule((int)gridDim.x, (int)blockIdx.x, sk.tiles, T_all, sdiv);
     for (int it = 0; it < sch.n_items; ++it) {  // ONE call site: the tile body is instantiated once
       const SkItem w = sk_item(sch, it, T_all);
@@ -729,7 +784,7 @@ template <int BM, int BN, int WM, int WN, int NS = 2>
 static hipError_t launch_cfg(const ConvArgs& a, hipStream_t s, bool* sk_query = nullptr) {
   const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + BN - 1) / BN;
   const long long tiles = (long long)tiles_m * tiles_n;
-  SkArgs sk = {nullptr, nullptr, 0};
+  SkArgs sk = {nullptr, nullptr, 0, 0};
   // Stream-K when the cost model says it pays (predict_launch): the launches whose last round of the CUs is poorly
   // filled.  ON by default for forward launches since the hand-off is write-through and the schedule keeps a plain
   // launch's locality (profiles/r03_negative_results.txt section 2 has the two builds that lost and why): 608x608
@@ -744,6 +799,31 @@ static hipError_t launch_cfg(const ConvArgs& a, hipStream_t s, bool* sk_query = 
     // the plain launch leaves 88 CUs with two tiles and 168 with one
     const long long per_cu = std::min<long long>(a.dgrad ? res_d : res_f, tiles / cus);
     const long long G = sk_slots > 0 ? sk_slots : (long long)cus * per_cu;
+    // PROBE (VY_CONV_KSPLIT=1; not bit-equal to the oracle's single chain): launches that leave most CUs empty run as
+    // tiles x S blocks, S = 4 for K >= 4096, 2 for K >= 1024 — the K-chunked summation order priced in DESIGN 9
+    {
+      static const int ks_on = getenv("VY_CONV_KSPLIT") ? atoi(getenv("VY_CONV_KSPLIT")) : 0;
+      const int T_all = a.ntaps * (a.Kc >> 5);
+      const double Kd = (double)a.ntaps * a.Kc;
+      int S = Kd >= 4096 ? 4 : (Kd >= 1024 ? 2 : 1);
+      if (ks_on > 1) S = S > 1 ? ks_on : 1;   // VY_CONV_KSPLIT=n > 1: that many chunks wherever the rule splits at all
+      const long long cap = (long long)cus * (a.dgrad ? res_d : res_f);
+      while (S > 1 && (tiles * S > cap || T_all % S != 0 || T_all / S < 4)) S >>= 1;
+      if (ks_on && !a.dgrad && S > 1 && tiles < cus && tiles * S * BM * BN * 4ll <= (long long)a.sk_bytes &&
+          tiles * S <= a.sk_nflags) {
+        if (sk_query) {
+          *sk_query = true;
+          return hipSuccess;
+        }
+        sk.partials = a.sk_partials;
+        sk.flags = a.sk_flags;
+        sk.tiles = (int)tiles;
+        sk.ksplit = S;
+        hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, false, NS, true>), dim3((unsigned)(tiles * S)), dim3(WM * WN * 64),
+                           0, s, a, tiles_n, sk);
+        return hipGetLastError();
+      }
+    }
     bool pays = false;
     if (const VyTileModel* tm = vy_tile_model(BM, BN))
       vy_predict_launch(a.M, a.N, (double)a.ntaps * a.Kc, *tm, sk_policy(a), &pays, cus);
