@@ -874,6 +874,10 @@ def main():
         result["also_416"] = {"frames_per_s": fps4, "ms_per_step": 1e3 * dt4 / args.steps, "batch": args.batch,
                               "whole_step_tflops": None if gflop4 is None else fps4 * gflop4 / 1e3,
                               "frac_of_fp32_mfma_peak": None if gflop4 is None else fps4 * gflop4 / 1e3 / FP32_MFMA_PEAK_TFLOPS}
+        # the reference's DEFAULT detect call: batch_size 1, data_shape 416 (detect_yolo3.py:55-57)
+        result["latency_batch1_416"] = dict(batch1_latency(net, x4[:1].contiguous(), torch, 416, args.classes),
+                                            note="one 416x416 frame resident in HBM -> 100 detection rows: the reference's default "
+                                                 "detect call (detect_yolo3.py:55-57 batch_size 1, data_shape 416)")
         del x4
 
     dog.arm("also_infer%d_split" % args.size)

@@ -121,6 +121,30 @@ VY_HD float vy_leaky(float x) { return fmaxf(x, 0.1f * x); }
 VY_HD float vy_bn_scale(float gamma, float var, float eps) { return gamma / sqrtf(var + eps); }
 VY_HD float vy_bn_shift(float beta, float mean, float scale) { return fmaf(-mean, scale, beta); }
 
+/* The pinned summation order of a forward convolution (oracle/ref_ops.c header): its K = taps x Cin
+ * products (Cin counted in 32-channel k-steps, so K = taps * 32 * ceil(Cin / 32)) are summed as S independent fp32 fma
+ * chains over S contiguous, equally long runs of k-steps, and the chains are then added in run order starting from +0:
+ *     out = (((+0 + P0) + P1) + P2) + P3.
+ * S depends on the layer's K only — never on the batch, the tile or the launch — so a frame gives the same bits whatever
+ * it is batched with:  K >= 4096 -> 4 (the eight 3x3 cells on 512 channels: the longest chains of the net, on its smallest
+ * maps), else 1.
+ * Why not one chain everywhere (rounds 1-5): a single chain per output element is serial; one frame's 13x13 / 19x19 maps
+ * give the chip 48 / 96 tiles of 64x64 for 256 CUs, each a 144-k-step chain — those launches are latency-bound.  Independent
+ * runs can go to different workgroups: one 416x416 frame 1.95 -> 1.62 ms, one 608x608 frame 2.23 -> 1.99 ms.
+ * Why not more runs, or runs for K >= 2048 too (measured, same box, profiles/r06_runs_ab.txt): a workgroup that computes
+ * all runs of a tile itself — every launch at batch 64 — has to park each finished chain in memory (there are no registers
+ * for a second accumulator tile) and read it back; all resident workgroups do that at the same moment, so it costs what
+ * moving those bytes at HBM speed costs: 0.03 % of the batch-64 step per (launch x parked chain).  4 / 2 runs for
+ * K >= 4096 / 2048: one 416 frame 1.50 ms but the batch-64 step -1.1 %; this rule: -0.7 %; two runs for K >= 4096: -0.35 %
+ * (one 416 frame 1.75 ms). */
+static inline int vy_conv_k_chunks(long long K) { return K >= 4096 ? 4 : 1; }
+/* ... for a conv of `taps` taps over `cch` 32-channel k-steps per tap: the runs must be equally long and a multiple of four
+ * k-steps (the kernels' LDS pipeline depth); a shape that is not (none of this net's) is summed as one chain. */
+static inline int vy_conv_runs(int taps, int cch) {
+  const int T = taps * cch, S = vy_conv_k_chunks((long long)T * 32);
+  return (S > 1 && T % (4 * S) == 0) ? S : 1;
+}
+
 /* IoU of two corner-format boxes, no +1 offset (mxnet box_nms / box_iou, corner format).
  * Returns 0 when the union is not positive (mxnet: u <= 0 ? 0 : i/u). */
 VY_HD float vy_box_iou(float ax1, float ay1, float ax2, float ay2, float bx1, float by1, float bx2,

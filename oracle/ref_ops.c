@@ -15,11 +15,15 @@
  * Layouts are the reference's: activations NCHW, conv weights OIHW, fp32 everywhere.
  *
  * Summation order (documented because the HIP kernels are held to bit-equality with it):
- *   conv accumulates ONE fp32 fma chain per output element, starting from +0, over taps (kh, kw)
- *   with kh outermost and, inside a tap, over the input channels; when Cin is a multiple of 8 the
- *   channels of each aligned group of 8 are visited in the order 0,4,1,5,2,6,3,7 (the order in
- *   which the fp32 matrix instruction of the device consumes a 32-byte channel group: its two
- *   half-waves hold channels 0-3 and 4-7 and alternate), otherwise (the 3-channel stem) ascending.
+ *   the products of an output element are visited over taps (kh, kw) with kh outermost and, inside a tap, over
+ *   the input channels; when Cin is a multiple of 8 the channels of each aligned group of 8 are visited in
+ *   the order 0,4,1,5,2,6,3,7 (the order in which the fp32 matrix instruction of the device consumes a
+ *   32-byte channel group: its two half-waves hold channels 0-3 and 4-7 and alternate), otherwise (the
+ *   3-channel stem) ascending.  That sequence, counted in k-steps of one tap x 32 channels, is cut into
+ *   S = vy_conv_k_chunks(taps * 32 * ceil(Cin / 32)) contiguous runs of equal length (include/vy_math.h:
+ *   4 for K >= 4096 — the 3x3 cells on 512 channels —, else 1); every run is ONE fp32 fma chain starting from +0, and the
+ *   runs are added in order starting from +0:  out = (((+0 + P0) + P1) + P2) + P3.  (Rounds 1-5 used a single
+ *   chain for every layer; round 6 cut the long ones so that one frame's small maps can use the whole chip.)
  *   A dot product's summation order is not part of the reference's definition (mxnet delegates it to
  *   MKL-DNN / cuDNN); fixing one order on both sides is what makes bit-equality testable.
  *   Bias/BN/activation follow.
@@ -54,14 +58,20 @@ int vyo_num_threads(void) {
 void vyo_conv2d(const float* x, int N, int C, int H, int W, const float* w, int O, int k, int s,
                 int p, const float* scale, const float* shift, int leaky, float* y) {
   const int Ho = (H + 2 * p - k) / s + 1, Wo = (W + 2 * p - k) / s + 1;
+  /* the runs of the pinned order (header): k-step t = tap * cch + (channel / 32), S runs of T / S k-steps */
+  const int cch = (C + 31) / 32, T = k * k * cch;
+  const int S = vy_conv_runs(k * k, cch);
+  const int run = T / S; /* T = 144 wherever S > 1 */
 #pragma omp parallel
   {
     float* acc = (float*)malloc(sizeof(float) * (size_t)Wo);
+    float* tot = (float*)malloc(sizeof(float) * (size_t)Wo);
 #pragma omp for collapse(3) schedule(static)
     for (int n = 0; n < N; ++n)
       for (int o = 0; o < O; ++o)
         for (int oy = 0; oy < Ho; ++oy) {
-          for (int ox = 0; ox < Wo; ++ox) acc[ox] = 0.0f;
+          for (int ox = 0; ox < Wo; ++ox) acc[ox] = 0.0f, tot[ox] = 0.0f;
+          int cur = 0; /* the run `acc` is the chain of */
           for (int kh = 0; kh < k; ++kh) {
             const int iy = oy * s + kh - p;
             if (iy < 0 || iy >= H) continue; /* zero taps: fma(0, w, acc) == acc */
@@ -71,6 +81,13 @@ void vyo_conv2d(const float* x, int N, int C, int H, int W, const float* w, int 
               while (lo < Wo && lo * s + kw - p < 0) ++lo;
               while (hi > lo && (hi - 1) * s + kw - p >= W) --hi;
               for (int cc = 0; cc < C; ++cc) {
+                if (S > 1 && (cc & 31) == 0) {
+                  /* a new k-step: close every run that ends before it (runs skipped entirely — all their taps fall
+                   * into the zero padding — contribute a chain that is still +0) */
+                  const int r = ((kh * k + kw) * cch + (cc >> 5)) / run;
+                  for (; cur < r; ++cur)
+                    for (int ox = 0; ox < Wo; ++ox) tot[ox] = tot[ox] + acc[ox], acc[ox] = 0.0f;
+                }
                 /* channel visiting order, see the header: 0,4,1,5,2,6,3,7 per group of 8 */
                 const int c = (C % 8 == 0) ? ((cc & ~7) | (((cc & 1) << 2) | ((cc & 7) >> 1))) : cc;
                 const float wv = w[(((size_t)o * C + c) * k + kh) * k + kw];
@@ -80,11 +97,14 @@ void vyo_conv2d(const float* x, int N, int C, int H, int W, const float* w, int 
               }
             }
           }
+          if (S > 1) /* the remaining runs (the last one always): (((+0 + P0) + P1) + P2) + P3 */
+            for (; cur < S; ++cur)
+              for (int ox = 0; ox < Wo; ++ox) tot[ox] = tot[ox] + acc[ox], acc[ox] = 0.0f;
           float* yr = y + (((size_t)n * O + o) * Ho + oy) * Wo;
           const float sc = scale ? scale[o] : 1.0f;
           const float sh = shift ? shift[o] : 0.0f;
           for (int ox = 0; ox < Wo; ++ox) {
-            float v = acc[ox];
+            float v = S > 1 ? tot[ox] : acc[ox];
             if (scale)
               v = fmaf(v, sc, sh);
             else if (shift)
@@ -94,6 +114,7 @@ void vyo_conv2d(const float* x, int N, int C, int H, int W, const float* w, int 
           }
         }
     free(acc);
+    free(tot);
   }
 }
 

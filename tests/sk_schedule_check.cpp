@@ -5,7 +5,8 @@
 //     block is in the same XCD group, and it ran the storing piece as an item that waits for nothing,
 //   * at most one HEAD and one TAIL per block, stores only from HEADs, loads only into TAILs, a TAIL is a block's last item,
 //   * the whole-tile waves of an XCD cover a contiguous run, block l taking tile w * gx + l,
-//   * shares are balanced: no block has more than one tile's worth of k-steps more than another.
+//   * shares are balanced: no block has more than one tile's worth of k-steps more than another,
+//   * with `align` (launches whose K is summed in runs): every cut point is a multiple of it.
 // usage: sk_schedule_check            -> "ok <cases> cases" or a message and exit code 1
 #include <cstdio>
 #include <cstdlib>
@@ -18,13 +19,13 @@ static int fail(const char* what, int tiles, int nblk, int T, int L) {
   return 1;
 }
 
-static int check(int tiles, int nblk, int T) {
+static int check(int tiles, int nblk, int T, int align = 1) {
   auto div = [](unsigned n, unsigned d) { return (int)(n / d); };
   std::vector<int> next_k(tiles, 0);          // how far each tile's chain has been computed (pieces must arrive in order)
   std::vector<int> stored_by(tiles, -1), stored_to(tiles, 0);
   std::vector<SkSchedule> sch(nblk);
   std::vector<long long> work(nblk, 0);
-  for (int L = 0; L < nblk; ++L) sch[L] = sk_schedule(nblk, L, tiles, T, div);
+  for (int L = 0; L < nblk; ++L) sch[L] = sk_schedule(nblk, L, tiles, T, div, align);
   // pass 1: everything that does not wait (whole tiles and HEADs), pass 2: the TAILs
   for (int pass = 0; pass < 2; ++pass) {
     for (int L = 0; L < nblk; ++L) {
@@ -34,6 +35,7 @@ static int check(int tiles, int nblk, int T) {
       for (int it = 0; it < s.n_items; ++it) {
         const SkItem w = sk_item(s, it, T);
         if (w.tile < 0 || w.tile >= tiles || w.kb < 0 || w.ke > T || w.kb >= w.ke) return fail("range", tiles, nblk, T, L);
+        if (w.kb % align || w.ke % align) return fail("cut point not aligned", tiles, nblk, T, L);
         if (it < s.D && w.tile != s.tx0 + it * s.gx + s.l) return fail("wave tile", tiles, nblk, T, L);
         heads += w.store_partial && !w.load_partial;
         tails += w.load_partial;
@@ -62,7 +64,7 @@ static int check(int tiles, int nblk, int T) {
     if (next_k[t] != T) return fail("tile not finished", tiles, nblk, T, t);
   long long lo = work[0], hi = work[0];
   for (int L = 0; L < nblk; ++L) lo = work[L] < lo ? work[L] : lo, hi = work[L] > hi ? work[L] : hi;
-  if (hi - lo > 2ll * T) return fail("unbalanced shares", tiles, nblk, T, (int)(hi - lo));
+  if (hi - lo > 2ll * T + 2ll * align) return fail("unbalanced shares", tiles, nblk, T, (int)(hi - lo));
   // vblk is a permutation of the blocks, XCD groups contiguous
   std::vector<int> seen(nblk, 0);
   for (int L = 0; L < nblk; ++L) {
@@ -83,6 +85,10 @@ int main() {
         if (t > g) {
           if (check(t, g, T)) return 1;
           ++cases;
+          if (T % 4 == 0) {  // launches whose K is summed in runs (K >= 2048: T = 72, 144): cuts at multiples of 4 k-steps
+            if (check(t, g, T, 4)) return 1;
+            ++cases;
+          }
         }
   // the test switch VY_CONV_SK_SLOTS and anything else: small and odd grids, tiles from just above the grid upwards
   unsigned long long st = 88172645463325252ull;
@@ -94,6 +100,8 @@ int main() {
     const int g = 1 + rnd(96), t = g + 1 + rnd(6 * g + 40), T = 1 + rnd(40);
     if (check(t, g, T)) return 1;
     ++cases;
+    if (check(t, g, 4 * T, 4) || check(t, g, 2 * T, 2)) return 1;
+    cases += 2;
   }
   for (int g = 1; g <= 40; ++g)
     for (int t = g + 1; t <= 5 * g + 3; ++t)

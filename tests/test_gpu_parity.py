@@ -585,6 +585,44 @@ def test_stream_k_hand_off_stays_bit_exact(slots, plain):
     assert " passed" in p.stdout
 
 
+@pytest.mark.parametrize("env", [
+    {"VY_CONV_KSPLIT": "0"},                                             # the runs one after the other in ONE workgroup (parked chains)
+    {"VY_CONV_KSPLIT": "0", "VY_CONV_FORCE": "128x128"},                 # ... on every tile of the kernel
+    {"VY_CONV_KSPLIT": "0", "VY_CONV_FORCE": "128x64"},
+    {"VY_CONV_KSPLIT": "0", "VY_CONV_FORCE": "64x64"},
+    {"VY_CONV_SK": "1", "VY_CONV_SK_SLOTS": "5", "VY_CONV_FORCE": "128x128"},   # stream-K pieces: parked chains handed from the
+    {"VY_CONV_SK": "1", "VY_CONV_SK_SLOTS": "13", "VY_CONV_FORCE": "64x64"},    # block that starts a tile to the one that finishes it
+    {"VY_CONV_SK": "0"},                                                 # no stream-K scratch at all: plain launches, parked chains
+], ids=lambda e: ",".join("%s=%s" % (k[8:], v) for k, v in e.items()))
+def test_runs_of_k_are_bit_exact_in_every_execution_form(env):
+    """The pinned summation order cuts K >= 4096 into 4 runs (include/vy_math.h vy_conv_k_chunks).  A launch executes
+    them in one of three forms — split-K (one workgroup per run; the default wherever the tiles leave half the chip empty:
+    every shape of this file), one workgroup running them in turn with the finished chains parked in scratch, or stream-K
+    pieces of that — and all three must give the oracle's bits.  The default run of this file covers split-K; this test forces
+    the other forms (and every tile of the kernel) in child processes."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.abspath(__file__)
+    p = subprocess.run([sys.executable, "-m", "pytest", here, "-q", "-x", "-m", "gpu", "-k",
+                        "heads_bit_exact or intermediate_cells or not_multiples_of_32"],
+                       env=dict(os.environ, **env), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900,
+                       universal_newlines=True)
+    assert p.returncode == 0, p.stdout[-3000:]
+    assert " passed" in p.stdout
+
+
+def test_split_k_launches_are_chosen_for_one_frame(voc_classes, synth20):
+    """One 416 x 416 frame (the reference's default detect call, detect_yolo3.py:55-57): the 13 x 13 cells on 512 channels
+    (48 tiles of 64 x 64) go out as split-K launches of 4 workgroups per tile; at batch 16 none does (the tiles fill the chip)."""
+    net = _net(voc_classes, synth20)
+    names = [r[0] for r in net.profile(frames(1, 416, seed=1))]
+    assert sum(1 for n in names if n.endswith("ks4")) == 8 and not any(n.endswith("ks2") for n in names), names
+    assert "stages.2.1.body.1|64x64ks4" in names and "yolo_blocks.0.tip|64x64ks4" in names
+    names16 = [r[0] for r in net.profile(frames(16, 416, seed=1))]
+    assert not any("ks" in n.split("|")[-1] for n in names16)
+
+
 @pytest.mark.parametrize("topk,post", [(400, 100), (-1, 100), (3000, 50)])
 def test_no_valid_candidate_at_all(voc_classes, topk, post):
     """Objectness biases of -30: every score is far below valid_thresh = 0.01, so box_nms has nothing to sort — all

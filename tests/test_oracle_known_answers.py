@@ -265,3 +265,71 @@ def test_operator_kit_covers_every_recalled_choice():
                    "background_id", "force_suppress_0", "force_suppress_1", "iou_at_thresh", "label_smooth_1", "no_wd",
                    "shrink", "enlarge", "mixed"):
         assert needle in names, needle
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The pinned summation order (oracle/ref_ops.c header, include/vy_math.h vy_conv_k_chunks): restated here in plain Python,
+# element by element, so that the C oracle's order is itself pinned by something that can be read in one screen.
+# ---------------------------------------------------------------------------------------------------------------------
+def _fma32(a, b, c):
+    """fp32 fma through an 80-bit intermediate: the product of two fp32 numbers is exact in 64 mantissa bits; the sum is
+    rounded once to 64 bits and once to 24 (a double rounding that can only differ from a true fma on an exact 40-bit tie)."""
+    return np.float32(np.longdouble(a) * np.longdouble(b) + np.longdouble(c))
+
+
+def _conv_element_in_pinned_order(x, w, n, o, oy, ox, stride, pad):
+    C, k = w.shape[1], w.shape[2]
+    cch = (C + 31) // 32
+    T = k * k * cch
+    K = T * 32
+    S = 4 if (K >= 4096 and T % 16 == 0) else 1      # (runs of equal length, a multiple of 4 k-steps: include/vy_math.h vy_conv_runs)
+    run = T // S
+    total, acc, cur = np.float32(0), np.float32(0), 0
+    for kh in range(k):
+        for kw in range(k):
+            for cc in range(C):
+                if cc % 32 == 0:
+                    r = ((kh * k + kw) * cch + cc // 32) // run
+                    while cur < r:
+                        total, acc, cur = np.float32(total + acc), np.float32(0), cur + 1
+                c = ((cc & ~7) | (((cc & 1) << 2) | ((cc & 7) >> 1))) if C % 8 == 0 else cc
+                iy, ix = oy * stride + kh - pad, ox * stride + kw - pad
+                xv = x[n, c, iy, ix] if 0 <= iy < x.shape[2] and 0 <= ix < x.shape[3] else np.float32(0)
+                acc = _fma32(xv, w[o, c, kh, kw], acc)
+    if S == 1:
+        return acc
+    while cur < S:
+        total, acc, cur = np.float32(total + acc), np.float32(0), cur + 1
+    return total
+
+
+@pytest.mark.parametrize("cin,k,runs", [(64, 3, 1), (128, 3, 1), (256, 3, 1), (512, 3, 4), (1024, 1, 1), (480, 3, 1), (448, 3, 1), (4096, 1, 4)])
+def test_conv_follows_the_pinned_runs_of_k(cin, k, runs):
+    """K = taps x Cin is summed in `runs` independent fp32 fma chains over equal runs of k-steps, added in order from +0
+    (4 runs for K >= 4096: the 3x3 cells on 512 channels; otherwise one chain)."""
+    from oracle import yolo3_oracle as O
+    rng = np.random.default_rng(cin + k)
+    x = rng.standard_normal((1, cin, 3, 3)).astype(np.float32)
+    w = (rng.standard_normal((2, cin, k, k)) / np.sqrt(cin * k * k)).astype(np.float32)
+    y = O.conv2d(x, w, 1, k // 2)
+    K = k * k * 32 * ((cin + 31) // 32)
+    assert (4 if (K >= 4096 and (K // 32) % 16 == 0) else 1) == runs
+    for (o, oy, ox) in [(0, 0, 0), (1, 1, 1), (0, 2, 1), (1, 0, 2)]:      # corners (whole runs in the padding), centre, edges
+        want = _conv_element_in_pinned_order(x, w, 0, o, oy, ox, 1, k // 2)
+        assert y[0, o, oy, ox] == want, (cin, k, o, oy, ox, y[0, o, oy, ox], want)
+    if runs > 1:
+        # ... and the order matters: ONE chain over the same products gives other bits somewhere in this tensor
+        one = np.zeros_like(y)
+        for o in range(2):
+            for oy in range(3):
+                for ox in range(3):
+                    acc = np.float32(0)
+                    for kh in range(k):
+                        for kw in range(k):
+                            for cc in range(cin):
+                                c = (cc & ~7) | (((cc & 1) << 2) | ((cc & 7) >> 1))
+                                iy, ix = oy + kh - k // 2, ox + kw - k // 2
+                                if 0 <= iy < 3 and 0 <= ix < 3:
+                                    acc = _fma32(x[0, c, iy, ix], w[o, c, kh, kw], acc)
+                    one[0, o, oy, ox] = acc
+        assert not np.array_equal(one, y) and np.abs(one - y).max() < 1e-5

@@ -35,6 +35,8 @@ for src, dst in [("%s_infer608_b64_bench.json", "%s_infer608_b64_bench.json"),
                  ("%s_layers_608_b64_split.txt", "%s_layers_608_b64_split.txt"),
                  ("%s_infer608_b64_split_bench_under_rocprof.json", "%s_infer608_b64_split_bench_under_rocprof.json"),
                  ("%s_small_batch_latency.txt", "%s_small_batch_latency.txt"),
+                 ("%s_small_batch_latency_416.txt", "%s_small_batch_latency_416.txt"),
+                 ("%s_layers_416_b1.txt", "%s_layers_416_b1.txt"),
                  ("%s_layers_608_b1.txt", "%s_layers_608_b1.txt"),
                  ("%s_layers_608_b1_split.txt", "%s_layers_608_b1_split.txt"),
                  ("%s_ab_split_train.txt", "%s_ab_split_train.txt"),
@@ -149,6 +151,10 @@ def write_summary():
     if lb:
         L.append("| one frame 608² (`latency_batch1`) | %s | %s | eager; HIP graph %s ms; %s of the roof |"
                  % (_f(1e3 / lb["eager_ms"]), _f(lb["eager_ms"], "%.3f"), _f(lb["hip_graph_ms"], "%.3f"), _f(lb.get("frac_of_fp32_mfma_peak"), "%.2f")))
+    lb4 = b.get("latency_batch1_416")
+    if lb4:
+        L.append("| one frame 416² (`latency_batch1_416`: the reference's default detect call) | %s | %s | eager; HIP graph %s ms; %s of the roof |"
+                 % (_f(1e3 / lb4["eager_ms"]), _f(lb4["eager_ms"], "%.3f"), _f(lb4["hip_graph_ms"], "%.3f"), _f(lb4.get("frac_of_fp32_mfma_peak"), "%.2f")))
     for key, label in (("also_hostfed608", "host-fed, pipelined (`also_hostfed608`)"), ("also_vid608", "configs[3]: 30 classes, host clip batch → scatter → net → gather (`also_vid608`)")):
         h = b.get(key)
         if h:
@@ -176,11 +182,22 @@ def write_summary():
             L.append("| %s (`%s`) | %s | %s | %s | %s / %s | %s |" % (label, key, _f(g["frames_per_s"]), _f(g["ms_per_step"], "%.2f"), _f(g.get("frac"), "%.3f"),
                                                                   _f(g.get("forward_ms"), "%.2f"), _f(g.get("backward_ms"), "%.2f"),
                                                                   _f(g["traffic"] / 1e9) if g.get("traffic") else "—"))
+    ms = b.get("also_train_multiscale")
+    if ms:
+        L.append("| the reference's DEFAULT mode: sizes %s, %d steps each (`also_train_multiscale`) | %s | %s | %s | — | — |"
+                 % ("/".join(str(v) for v in ms["sizes_in_order"]), ms["interval"], _f(ms["frames_per_s"]), _f(ms["ms_per_step"], "%.2f"), _f(ms.get("frac"), "%.3f")))
     if t:
         L.append("| `--mode train` as the headline | %s | %s | %s | %s / %s | %s |"
                  % (_f(t["value"]), _f(t["ms_per_step"], "%.2f"), _f((t.get("roofline") or {}).get("frac"), "%.3f"),
                     _f((t.get("step_split") or {}).get("forward_ms"), "%.2f"), _f((t.get("step_split") or {}).get("backward_ms"), "%.2f"),
                     _f((t.get("roofline") or {}).get("traffic", 0) / 1e9) if (t.get("roofline") or {}).get("traffic") else "—"))
+    if ms:
+        L += ["", "### Multi-scale training, per size (rank 0; re-plan = workspace bind + border zeroing at every size change; %.2f %% of the sequence)"
+              % (100 * ms["replan_share"]), "", "| size | frames/s | steady ms/step | whole-step fraction of the roof | re-plan ms | share of its 10-step window |", "|---|---|---|---|---|---|"]
+        for sz in sorted(ms["per_size"], key=int):
+            v = ms["per_size"][sz]
+            L.append("| %s | %s | %s | %s | %s | %s %% |" % (sz, _f(v["frames_per_s"]), _f(v["steady_ms_per_step"], "%.2f"), _f(v["frac_whole_step"], "%.3f"),
+                                                          _f(v["replan_ms"], "%.2f"), _f(100 * v["replan_share_of_window"], "%.2f")))
     # rocprofv3 kernel stats: the ten largest kernels of the profiled inference command
     ks = os.path.join(P, "%s_infer608_b64_kernel_stats.csv" % out)
     if os.path.exists(ks):

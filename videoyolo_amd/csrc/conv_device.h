@@ -48,6 +48,13 @@ __device__ __forceinline__ void buf_store_f32x4_sc1(f32x4 v, __amdgpu_buffer_rsr
 __device__ __forceinline__ f32x4 buf_load_f32x4_sc1(__amdgpu_buffer_rsrc_t rsrc, unsigned voff) {
   return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 16));
 }
+// the same with the default cache policy (write-through L1, write-back L2): bytes the SAME lanes read back later
+__device__ __forceinline__ void buf_store_f32x4(f32x4 v, __amdgpu_buffer_rsrc_t rsrc, unsigned voff) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(vy_u32x4, v), rsrc, voff, 0, 0);
+}
+__device__ __forceinline__ f32x4 buf_load_f32x4(__amdgpu_buffer_rsrc_t rsrc, unsigned voff) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 0));
+}
 #endif
 
 __device__ __forceinline__ unsigned fd_div(unsigned n, const VyFastDiv f) {

@@ -59,10 +59,11 @@ struct SkArgs {
 
 // One tile of the implicit GEMM, k-steps [kb, ke): from zero or (SK) from the previous block's partial sums, to the
 // epilogue or (SK) to this block's partial slab.  `Args` is ConvArgs in the address space the caller reads it from.
-template <int BM, int BN, int WM, int WN, bool DGRAD, int NS, bool SK, typename Args>
+template <int BM, int BN, int WM, int WN, bool DGRAD, int NS, bool SK, bool CK, typename Args>
 __device__ __forceinline__ void conv_tile(Args& a, const int tiles_n, const SkArgs& sk, unsigned char* smem,
                                           const int vblk, const int v, const int kb, const int ke,
-                                          const bool load_partial, const bool store_partial, const int ks_reduce = 0) {
+                                          const bool load_partial, const bool store_partial, const int ks_reduce = 0,
+                                          const int ch_len = 0, const int n_tiles = 0) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
   constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
@@ -343,6 +344,57 @@ __device__ __forceinline__ void conv_tile(Args& a, const int tiles_n, const SkAr
       mfma_step(cur, 3);
     }
   };
+  // ---- runs of the pinned summation order (include/vy_math.h vy_conv_k_chunks): every ch_len k-steps (absolute position in
+  // the tile's K sequence) the chain in `acc` is complete.  It is PARKED — 16-byte stores into slot c of the
+  // tile's scratch (a.ck_scratch: [run c][tile][BM x BN]), fire and forget: no wait, the DMA pipeline keeps running — and
+  // `acc` restarts from +0.  Stream-K instances store write-through (sc1) and read back past L1: a chain parked by the
+  // block that starts a tile is read by the block that finishes it; plain instances use the default policy.  (Measured:
+  // the stores are 0.2 % of the batch-64 step either way; what costs is reading the chains back — see the end of the tile.)  When the tile's last run is done its workgroup reads the parked chains back and adds them in
+  // run order, (((+0 + P0) + P1) + P2) + acc.  The lanes that read a slot are the lanes that wrote it — or, for a stream-K
+  // tile, lanes of the block that finishes it, after the hand-off flag (the HEAD block drains its stores before raising it).
+  // (First build: a running sum R += P_c at every boundary.  The load in it has to return before the next MFMA, and
+  // loads return in order — so every boundary drained the LDS-DMA queue: +13 us on a 75 us launch with one block per CU.)
+  // Boundaries sit at multiples of NS k-steps from kb (ch_len % 4 == 0; the stream-K schedule cuts chunked launches at
+  // multiples of 4).  ch_len == 0: one run (K < 2048, data gradients, and the workgroups of a split-K launch).
+  // CK: instances for the launches whose K is summed in runs.  A template parameter, not just ch_len > 0: with the run
+  // bookkeeping compiled into every forward instance the batch-64 step lost 0.6 % on launches that have ONE run (more
+  // scalar state in the k-loop, 11 more spilled SGPRs in the stream-K instances; same-box A/B, profiles/r06_runs_ab.txt)
+  const bool chunked = CK && !DGRAD && ch_len > 0;
+  int nb = 0x7fffffff;  // k-step (relative to kb) of the next boundary
+  int run = 0;          // the run `acc` is the chain of
+  if (chunked) {
+    // (an integer division runs on the vector unit: its result is made scalar again by hand, or the loop bounds below —
+    // and with them every address of the k-loop — would count as per-lane values)
+    run = __builtin_amdgcn_readfirstlane(kb / ch_len);
+    const int r = kb - run * ch_len;
+    if (r == 0 && kb > 0) --run;  // a piece that starts ON a boundary holds the finished chain of the run before it
+    nb = __builtin_amdgcn_readfirstlane((r == 0 && kb > 0) ? 0 : ch_len - r);
+  }
+  auto ck_slot = [&](int c) {
+    return __builtin_amdgcn_make_buffer_rsrc(a.ck_scratch + ((size_t)c * n_tiles + v) * (BM * BN), 0, BM * BN * 4, 0x00020000);
+  };
+  auto boundary = [&]() {
+    const __amdgpu_buffer_rsrc_t wr = ck_slot(run);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          f32x4 p4;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            p4[e] = acc[i][j][q * 4 + e];
+            acc[i][j][q * 4 + e] = 0.0f;
+          }
+          const unsigned off = (unsigned)((((i * TN + j) * 4 + q) * NT + tid) * 16);
+#if !(defined(VY_CK_ABL) && (VY_CK_ABL & 2))  // measurement builds: what do the parking stores cost?
+          if constexpr (SK) buf_store_f32x4_sc1(p4, wr, off);
+          else buf_store_f32x4(p4, wr, off);
+#endif
+        }
+    ++run;
+  };
   using W0 = std::integral_constant<int, 0>;
   if constexpr (NS == 2) {
     advance();
@@ -352,8 +404,16 @@ __device__ __forceinline__ void conv_tile(Args& a, const int tiles_n, const SkAr
     using P1 = std::integral_constant<int, 1>;
     int t = 0;
     for (; t + 2 < T; t += 2) {
+      if (chunked && t == nb) {  // (uniform: a scalar compare and branch per pair of k-steps)
+        boundary();
+        nb += ch_len;
+      }
       ktile(P0{}, std::true_type{}, W0{});
       ktile(P1{}, std::true_type{}, W0{});
+    }
+    if (chunked && t == nb && t < T) {  // (a boundary exactly where the peeled tail starts)
+      boundary();
+      nb += ch_len;
     }
     if (t + 2 == T) {
       ktile(P0{}, std::true_type{}, W0{});
@@ -384,12 +444,20 @@ __device__ __forceinline__ void conv_tile(Args& a, const int tiles_n, const SkAr
     using S3 = std::integral_constant<int, 3>;
     int t = 0;
     for (; t + 7 <= T; t += 4) {  // all four have a k-step to prefetch (t + 3 + 3 < T)
+      if (chunked && t == nb) {
+        boundary();
+        nb += ch_len;
+      }
       ktile(S0{}, std::true_type{}, W2{});
       ktile(S1{}, std::true_type{}, W2{});
       ktile(S2{}, std::true_type{}, W2{});
       ktile(S3{}, std::true_type{}, W2{});
     }
     for (; t < T; t += 4) {
+      if (chunked && t == nb) {
+        boundary();
+        nb += ch_len;
+      }
       kstep(S0{}, t);
       if (t + 1 < T) kstep(S1{}, t + 1);
       if (t + 2 < T) kstep(S2{}, t + 2);
@@ -398,6 +466,55 @@ __device__ __forceinline__ void conv_tile(Args& a, const int tiles_n, const SkAr
   }
 
   VY_TRACE(2)
+#if defined(VY_CK_ABL) && (VY_CK_ABL & 1)  // measurement builds: what does reading the parked chains back cost?
+  if (false) {
+#else
+  if (chunked && !(SK && store_partial) && run > 0) {
+#endif
+    // the tile's last run is complete: out = (((+0 + P0) + P1) + P2) + acc, the parked chains read back in run order.
+    // Memory-level parallelism is what this costs (all resident blocks of a launch reach it at about the same time, so the
+    // neighbour on the CU does not hide it): the three slots of TWO accumulator tiles are requested before anything is
+    // added — 24 loads of 16 bytes per lane in flight — through descriptors whose range is 0 for the runs this tile does
+    // not have (those loads return +0 without touching memory, and x + (+0) = x for every x a chain from +0 can hold: a
+    // chain never yields -0).  One fixed, branch-free sequence for 2 and 4 runs.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's own parking stores are in L2 (the DMA queue is empty here anyway)
+    constexpr int MAXP = 3;  // vy_conv_k_chunks() - 1 at most
+    __amdgpu_buffer_rsrc_t slot[MAXP];
+#pragma unroll
+    for (int c = 0; c < MAXP; ++c)
+      slot[c] = __builtin_amdgcn_make_buffer_rsrc(a.ck_scratch + ((size_t)(c < run ? c : 0) * n_tiles + v) * (BM * BN), 0,
+                                                  c < run ? BM * BN * 4 : 0, 0x00020000);
+    constexpr int NG = TM * TN, GSTEP = NG >= 2 ? 2 : 1;
+#pragma unroll
+    for (int g0 = 0; g0 < NG; g0 += GSTEP) {
+      f32x4 pk[GSTEP][MAXP][4];
+#pragma unroll
+      for (int gg = 0; gg < GSTEP; ++gg)
+#pragma unroll
+        for (int c = 0; c < MAXP; ++c)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const unsigned off = (unsigned)((((g0 + gg) * 4 + q) * NT + tid) * 16);
+            // stream-K instances park and read back write-through / past L1 throughout (a chain may have been parked by
+            // the block that started the tile); plain instances with the default policy (the same lanes read it back)
+            if constexpr (SK) pk[gg][c][q] = buf_load_f32x4_sc1(slot[c], off);
+            else pk[gg][c][q] = buf_load_f32x4(slot[c], off);
+          }
+#pragma unroll
+      for (int gg = 0; gg < GSTEP; ++gg) {
+        const int gi = (g0 + gg) / TN, gj = (g0 + gg) % TN;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float t = 0.0f;
+#pragma unroll
+            for (int c = 0; c < MAXP; ++c) t = t + pk[gg][c][q][e];
+            acc[gi][gj][q * 4 + e] = t + acc[gi][gj][q * 4 + e];
+          }
+      }
+    }
+  }
   if constexpr (SK) {
     if (ks_reduce > 0) {
       // split-K: this block ran the LAST chunk.  The blocks of chunks 0 .. ks_reduce - 1 (slab / flag index c * tiles + v)
@@ -424,10 +541,8 @@ __device__ __forceinline__ void conv_tile(Args& a, const int tiles_n, const SkAr
               const __amdgpu_buffer_rsrc_t slab = __builtin_amdgcn_make_buffer_rsrc(
                   sk.partials + (size_t)(c * sk.tiles + v) * (BM * BN), 0, BM * BN * 4, 0x00020000);
               const f32x4 p4 = buf_load_f32x4_sc1(slab, off);
-              if (c == 0) t4 = p4;
-              else
 #pragma unroll
-                for (int e = 0; e < 4; ++e) t4[e] = t4[e] + p4[e];
+              for (int e = 0; e < 4; ++e) t4[e] = t4[e] + p4[e];   // (((+0 + P0) + P1) + ...: the pinned order, vy_math.h)
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e) acc[i][j][q * 4 + e] = t4[e] + acc[i][j][q * 4 + e];
@@ -613,7 +728,7 @@ __device__ __forceinline__ void conv_tile(Args& a, const int tiles_n, const SkAr
 #endif  // __HIP_DEVICE_COMPILE__
 }
 
-template <int BM, int BN, int WM, int WN, bool DGRAD, int NS = 2, bool SK = false>
+template <int BM, int BN, int WM, int WN, bool DGRAD, int NS = 2, bool SK = false, bool CK = false>
 // SK = chain-preserving stream-K.  A plain launch hands whole tiles to the CUs, so a launch of 2.66 x 256 tiles costs three
 // rounds.  The SK instance is launched with exactly as many blocks as the chip holds; the sequence of all k-steps (tile
 // 0's, tile 1's, ...) is cut into equal contiguous shares, one per block, so a block owns [the tail of a tile][whole
@@ -648,24 +763,25 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_kernel(const ConvA
 
 
   if constexpr (!SK) {
-    conv_tile<BM, BN, WM, WN, DGRAD, NS, SK, const ConvArgs>(a, tiles_n, sk, smem, vblk, vblk, 0, T_all, false, false);
+    conv_tile<BM, BN, WM, WN, DGRAD, NS, SK, CK, const ConvArgs>(a, tiles_n, sk, smem, vblk, vblk, 0, T_all, false, false, 0,
+                                                                 CK ? a.k_chunk : 0, (int)gridDim.x);
   } else {
     // which k-steps of which tiles: sk_schedule.h (shared with the host-side checker of the CPU test suite).
     // (32-bit arithmetic made scalar again by hand: tiles x blocks < 2^31 is checked by the launcher; a 64-bit division
     // is expanded into vector code with control flow and its results then count as per-lane values)
     auto sdiv = [](unsigned n, unsigned d) { return (int)__builtin_amdgcn_readfirstlane((int)(n / d)); };
-    if (sk.ksplit > 0) {
+    if (!CK && sk.ksplit > 0) {
       typedef const __attribute__((address_space(4))) ConvArgs KArgs;
       KArgs* ap = (KArgs*)__builtin_amdgcn_kernarg_segment_ptr();
       const int chunk = sdiv((unsigned)vblk, (unsigned)sk.tiles), tile = vblk - chunk * sk.tiles;
       const int kb = sdiv((unsigned)(chunk * T_all), (unsigned)sk.ksplit), ke = sdiv((unsigned)((chunk + 1) * T_all), (unsigned)sk.ksplit);
       const bool last = chunk == sk.ksplit - 1;
       // (the slab / flag of chunk c's block is index c * tiles + tile == its vblk)
-      conv_tile<BM, BN, WM, WN, DGRAD, NS, SK, KArgs>(*ap, tiles_n, sk, smem, vblk, tile, kb, ke, false, !last,
+      conv_tile<BM, BN, WM, WN, DGRAD, NS, SK, false, KArgs>(*ap, tiles_n, sk, smem, vblk, tile, kb, ke, false, !last,
                                                        last ? sk.ksplit - 1 : 0);
       return;
     }
-    const SkSchedule sch = sk_schedule((int)gridDim.x, (int)blockIdx.x, sk.tiles, T_all, sdiv);
+    const SkSchedule sch = sk_schedule((int)gridDim.x, (int)blockIdx.x, sk.tiles, T_all, sdiv, (CK && a.k_chunk > 0) ? NS : 1);
     for (int it = 0; it < sch.n_items; ++it) {  // ONE call site: the tile body is instantiated once
       const SkItem w = sk_item(sch, it, T_all);
       const int tile = w.tile, kb = w.kb, ke = w.ke;
@@ -676,7 +792,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_kernel(const ConvA
       typedef const __attribute__((address_space(4))) ConvArgs KArgs;
       KArgs* ap = (KArgs*)__builtin_amdgcn_kernarg_segment_ptr();  // ConvArgs is the first argument
       asm volatile("" : "+s"(ap));
-      conv_tile<BM, BN, WM, WN, DGRAD, NS, SK, KArgs>(*ap, tiles_n, sk, smem, vblk, tile, kb, ke, ld, st);
+      conv_tile<BM, BN, WM, WN, DGRAD, NS, SK, CK, KArgs>(*ap, tiles_n, sk, smem, vblk, tile, kb, ke, ld, st, 0, CK ? ap->k_chunk : 0,
+                                                          sk.tiles);
     }
   }
 #endif  // __HIP_DEVICE_COMPILE__
@@ -781,10 +898,21 @@ static VySkPolicy sk_policy(const ConvArgs& a) {
 
 // `sk_query` != nullptr: nothing is launched, *sk_query tells whether the launch would be a stream-K one (the profile's label)
 template <int BM, int BN, int WM, int WN, int NS = 2>
-static hipError_t launch_cfg(const ConvArgs& a, hipStream_t s, bool* sk_query = nullptr) {
+static hipError_t launch_cfg(const ConvArgs& a_in, hipStream_t s, bool* sk_query = nullptr, int* ks_query = nullptr) {
+  ConvArgs a = a_in;
   const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + BN - 1) / BN;
   const long long tiles = (long long)tiles_m * tiles_n;
   SkArgs sk = {nullptr, nullptr, 0, 0};
+  // the runs of the pinned summation order (forward launches only; gradients are not held to the oracle's bits)
+  const int T_runs = a.ntaps * (a.Kc >> 5);
+  const int ksplit_S = a.dgrad ? 1 : vy_conv_runs(a.ntaps, a.Kc >> 5);
+  a.k_chunk = 0;
+  if (ks_query) *ks_query = 0;
+  if (ksplit_S > 1) {
+    a.k_chunk = T_runs / ksplit_S;
+    // a workgroup that runs more than one run of a tile parks the finished runs' sum in the tile's scratch
+    if (!sk_query && (!a.ck_scratch || (ksplit_S - 1) * tiles * BM * BN * 4ll > (long long)a.ck_bytes)) return hipErrorInvalidValue;
+  }
   // Stream-K when the cost model says it pays (predict_launch): the launches whose last round of the CUs is poorly
   // filled.  ON by default for forward launches since the hand-off is write-through and the schedule keeps a plain
   // launch's locality (profiles/r03_negative_results.txt section 2 has the two builds that lost and why): 608x608
@@ -799,28 +927,27 @@ static hipError_t launch_cfg(const ConvArgs& a, hipStream_t s, bool* sk_query = 
     // the plain launch leaves 88 CUs with two tiles and 168 with one
     const long long per_cu = std::min<long long>(a.dgrad ? res_d : res_f, tiles / cus);
     const long long G = sk_slots > 0 ? sk_slots : (long long)cus * per_cu;
-    // PROBE (VY_CONV_KSPLIT=1; not bit-equal to the oracle's single chain): launches that leave most CUs empty run as
-    // tiles x S blocks, S = 4 for K >= 4096, 2 for K >= 1024 — the K-chunked summation order priced in DESIGN 9
-    {
-      static const int ks_on = getenv("VY_CONV_KSPLIT") ? atoi(getenv("VY_CONV_KSPLIT")) : 0;
-      const int T_all = a.ntaps * (a.Kc >> 5);
-      const double Kd = (double)a.ntaps * a.Kc;
-      int S = Kd >= 4096 ? 4 : (Kd >= 1024 ? 2 : 1);
-      if (ks_on > 1) S = S > 1 ? ks_on : 1;   // VY_CONV_KSPLIT=n > 1: that many chunks wherever the rule splits at all
-      const long long cap = (long long)cus * (a.dgrad ? res_d : res_f);
-      while (S > 1 && (tiles * S > cap || T_all % S != 0 || T_all / S < 4)) S >>= 1;
-      if (ks_on && !a.dgrad && S > 1 && tiles < cus && tiles * S * BM * BN * 4ll <= (long long)a.sk_bytes &&
-          tiles * S <= a.sk_nflags) {
+    // Split-K: a launch whose K is summed in S > 1 runs (the pinned order, vy_math.h) and whose tiles leave at least half
+    // of the CUs empty goes out as tiles x S workgroups, one run each; the last run's workgroup adds the others' sums in
+    // run order (conv_tile, ks_reduce) — the same arithmetic as one workgroup running the runs one after the other.
+    // Measured (profiles/r06_ksplit_probe.txt, one frame): 13x13 / 19x19 3x3 cells on 512 channels 75 -> 33 / 47 us; a
+    // launch of 184 tiles cut in two lost 4 %: hence tiles <= CUs / 2.  VY_CONV_KSPLIT=0: never.
+    if (ksplit_S > 1) {
+      static const int ks_on = getenv("VY_CONV_KSPLIT") ? atoi(getenv("VY_CONV_KSPLIT")) : 1;
+      const long long cap = (long long)cus * res_f;
+      if (ks_on && sk_slots == 0 && 2 * tiles <= cus && tiles * ksplit_S <= cap && tiles * ksplit_S * BM * BN * 4ll <= (long long)a.sk_bytes &&
+          tiles * ksplit_S <= a.sk_nflags) {
         if (sk_query) {
-          *sk_query = true;
+          *sk_query = false;
+          if (ks_query) *ks_query = ksplit_S;
           return hipSuccess;
         }
         sk.partials = a.sk_partials;
         sk.flags = a.sk_flags;
         sk.tiles = (int)tiles;
-        sk.ksplit = S;
-        hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, false, NS, true>), dim3((unsigned)(tiles * S)), dim3(WM * WN * 64),
-                           0, s, a, tiles_n, sk);
+        sk.ksplit = ksplit_S;
+        hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, false, NS, true>), dim3((unsigned)(tiles * ksplit_S)),
+                           dim3(WM * WN * 64), 0, s, a, tiles_n, sk);
         return hipGetLastError();
       }
     }
@@ -839,6 +966,9 @@ static hipError_t launch_cfg(const ConvArgs& a, hipStream_t s, bool* sk_query = 
       if (a.dgrad)
         hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, true, NS, true>), dim3((unsigned)G), dim3(WM * WN * 64), 0, s,
                            a, tiles_n, sk);
+      else if (a.k_chunk > 0)
+        hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, false, NS, true, true>), dim3((unsigned)G), dim3(WM * WN * 64), 0, s,
+                           a, tiles_n, sk);
       else
         hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, false, NS, true>), dim3((unsigned)G), dim3(WM * WN * 64), 0, s,
                            a, tiles_n, sk);
@@ -852,6 +982,9 @@ static hipError_t launch_cfg(const ConvArgs& a, hipStream_t s, bool* sk_query = 
   if (a.dgrad)
     hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, true, NS>), dim3(tiles_m * tiles_n), dim3(WM * WN * 64), 0, s,
                        a, tiles_n, sk);
+  else if (a.k_chunk > 0)
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, false, NS, false, true>), dim3(tiles_m * tiles_n), dim3(WM * WN * 64), 0,
+                       s, a, tiles_n, sk);
   else
     hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, false, NS>), dim3(tiles_m * tiles_n), dim3(WM * WN * 64), 0, s,
                        a, tiles_n, sk);
@@ -923,32 +1056,47 @@ static VyFastDiv make_fastdiv(unsigned d) {
 }
 
 // tile choice -> template instance; `sk_query`: see launch_cfg
-static hipError_t run_cfg(const ConvArgs& a, hipStream_t s, bool* sk_query) {
+static hipError_t run_cfg(const ConvArgs& a, hipStream_t s, bool* sk_query, int* ks_query = nullptr) {
   int bm, bn;
   select_cfg(a, &bm, &bn);
   if (sk_query) *sk_query = false;
+  if (ks_query) *ks_query = 0;
+  // (the 16x16-wave-tile kernel computes ONE chain: launches whose K is summed in runs stay on the 32x32 tiles)
+  const bool runs = !a.dgrad && vy_conv_runs(a.ntaps, a.Kc >> 5) > 1;
+  if (bm == 32 && runs) bm = bn = 64;
   if (bm == 32) return sk_query ? hipSuccess : vy_launch_conv_s16(a, bm, bn, s);
   // experiment switch: VY_CONV_S16=1 sends a forced tile (VY_CONV_FORCE) through the 16x16x4 kernel where it has the instance
   static const int s16_forced = getenv("VY_CONV_S16") ? atoi(getenv("VY_CONV_S16")) : 0;
-  if (s16_forced && !sk_query && !a.dgrad && (bm % 32 == 0) && (bn == 64 || bn == 96)) {
+  if (s16_forced && !runs && !sk_query && !a.dgrad && (bm % 32 == 0) && (bn == 64 || bn == 96)) {
     const hipError_t e = vy_launch_conv_s16(a, bm, bn, s);
     if (e != hipErrorInvalidValue) return e;
   }
-  if (bn == 32) return launch_cfg<128, 32, 4, 1>(a, s, sk_query);
-  if (bm == 128 && bn == 64) return launch_cfg<128, 64, 2, 2>(a, s, sk_query);
+  if (bn == 32) return launch_cfg<128, 32, 4, 1>(a, s, sk_query, ks_query);
+  if (bm == 128 && bn == 64) return launch_cfg<128, 64, 2, 2>(a, s, sk_query, ks_query);
   if (bm == 64) {
     // few blocks (at most two per CU) and a k-loop long enough to fill it: the four-stage pipeline
     static const int deep = getenv("VY_CONV_DEEP") ? atoi(getenv("VY_CONV_DEEP")) : 512;
     const long long nb = (long long)((a.M + 63) / 64) * ((a.N + 63) / 64);
-    if (nb <= deep && a.ntaps * (a.Kc >> 5) >= 8) return launch_cfg<64, 64, 2, 2, 4>(a, s, sk_query);
-    return launch_cfg<64, 64, 2, 2>(a, s, sk_query);
+    if (nb <= deep && a.ntaps * (a.Kc >> 5) >= 8) return launch_cfg<64, 64, 2, 2, 4>(a, s, sk_query, ks_query);
+    return launch_cfg<64, 64, 2, 2>(a, s, sk_query, ks_query);
   }
-  return launch_cfg<128, 128, 2, 2>(a, s, sk_query);
+  return launch_cfg<128, 128, 2, 2>(a, s, sk_query, ks_query);
 }
 
 bool vy_conv_streamk(const ConvArgs& a) {
   bool sk = false;
   return run_cfg(a, nullptr, &sk) == hipSuccess && sk;
+}
+
+int vy_conv_ksplit(const ConvArgs& a) {
+  bool sk = false;
+  int ks = 0;
+  return run_cfg(a, nullptr, &sk, &ks) == hipSuccess ? ks : 0;
+}
+
+size_t vy_conv_chunk_scratch_bytes(long long M, int N, int runs) {
+  const long long m = (M + 127) / 128 * 128, n = ((long long)N + 127) / 128 * 128;
+  return runs > 1 ? (size_t)((runs - 1) * m * n * 4) : 0;
 }
 
 hipError_t vy_launch_conv_igemm(const ConvArgs& a_in, hipStream_t s) {

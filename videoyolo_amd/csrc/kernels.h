@@ -62,6 +62,14 @@ struct ConvArgs {
   // the test switches VY_SPLIT_ALWAYS / VY_SPLIT_WINO as the net read them ONCE at the start of this forward / step
   // (value + 1; 0: not read — vy_conv_*_pays read the environment themselves, e.g. for a probe's hand-made ConvArgs)
   int env_split_always_p1, env_wino_mode_p1;
+  // The pinned summation order cuts long K into S = vy_conv_k_chunks(K) runs (include/vy_math.h).  A workgroup that computes
+  // more than one run of a tile parks every finished chain in this scratch ([run][tile][BM x BN] floats: written and read
+  // back by the same lanes, or handed from the block that starts a stream-K tile to the one that finishes it,
+  // write-through) and adds them in run order at the end.  Nullable when no conv of the net has S > 1; a launch with S > 1
+  // and no scratch is refused.  k_chunk: filled by the launcher (k-steps per run; 0: one run)
+  float* ck_scratch;
+  unsigned long long ck_bytes;
+  int k_chunk;
   // CUs of the device this launch goes to, as the net resolved them ONCE (vy_net::cus: at its first sizing call, checked
   // against the workspace's device at bind time) — every cost-model choice of a net counts rounds in the same chip whatever
   // the calling thread's current device is.  0: not set (a probe's hand-made ConvArgs): vy_cu_count() of the current device
@@ -83,6 +91,8 @@ int vy_cu_count_of(int device);                           // ... of a given devi
 int vy_cu_count_of_ptr(const void* dev_ptr);              // ... of the device that owns an allocation (0: not a device pointer)
 static inline int vy_args_cus(const ConvArgs& a) { return a.cus > 0 ? a.cus : vy_cu_count(); }
 bool vy_conv_streamk(const ConvArgs& a);                  // ... and whether it will be a stream-K launch (label "<BM>x<BN>sk")
+int vy_conv_ksplit(const ConvArgs& a);                    // ... or a split-K one: the S workgroups per tile (label "<BM>x<BN>ks<S>"), else 0
+size_t vy_conv_chunk_scratch_bytes(long long M, int N, int runs);   // ck_scratch bytes a conv of M x N outputs summed in `runs` runs may need (any tile)
 
 // stream-K is enabled per net only after this has seen the MI355X's SPX placement (8 XCDs, blocks L and L + 8 on one
 // XCD, 256 CUs) on the current device; `scratch_dev`: >= 512 words the probe may use and leaves zeroed.  Synchronises `s`

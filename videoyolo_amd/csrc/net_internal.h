@@ -13,6 +13,7 @@
 
 #include "../../include/vyolo.h"
 #include "kernels.h"
+#include "../../include/vy_math.h"
 
 // error channel (defined in net.hip)
 int vy_fail(int code, const char* fmt, ...);
@@ -80,6 +81,7 @@ struct vy_net {
   size_t ws_bytes = 0;
   int B = 0, H = 0, W = 0;
   size_t fold_desc_off = 0, det_scratch_off = 0, planes_off = 0, sk_off = 0;  // byte offsets in workspace
+  size_t ck_off = 0, ck_bytes = 0;  // running-sum scratch of the convs whose K is summed in runs (conv_igemm.hip)
   bool fold_uploaded = false;
   bool keep_activations = false;  // vy_net_set_keep_activations: inference planes are not recycled (parity taps)
   bool planes_shared = false;     // the committed plan recycles planes (read_activation is then meaningless)
@@ -368,6 +370,18 @@ struct vy_net {
     off += al(vy_det_scratch_bytes(b, n_items, num_class));
     const size_t sk_o = off;  // stream-K scratch of the conv launches (conv_igemm.hip): flags first, then the slabs
     off += al((size_t)VY_SK_FLAGS * sizeof(unsigned)) + al(VY_SK_PARTIAL_BYTES);
+    // parked chains of the convs whose K is summed in runs (vy_conv_k_chunks; conv_igemm.hip `boundary`): runs - 1 tile-shaped
+    // slabs per output tile of the conv that needs most
+    const size_t ck_o = off;
+    size_t ck_b = 0;
+    for (const ConvT& c : convs) {
+      const int runs = c.is_stem ? 1 : vy_conv_runs(c.k * c.k, (c.cin + 31) >> 5);
+      if (runs < 2) continue;
+      const PlaneT& op = planes[c.out_plane];
+      const long long Mo = (long long)b * cdiv(h, op.div) * cdiv(w, op.div);
+      ck_b = std::max(ck_b, vy_conv_chunk_scratch_bytes(Mo, c.cout, runs));
+    }
+    off += al(ck_b);
     const size_t wsp_off = off;  // split-fp32 weight images (conv mode VY_CONV_SPLIT_BF16X3 only)
     for (ConvT& c : convs) {
       const bool el = split_eligible(c);
@@ -401,6 +415,8 @@ struct vy_net {
       fold_desc_off = fold_off;
       det_scratch_off = det_off;
       sk_off = sk_o;
+      ck_off = ck_o;
+      ck_bytes = ck_b;
       wsplit_off = wsp_off;
       split_dirty = dsplit_dirty = wino_dirty = true;
       planes_off = pl_off;
@@ -478,6 +494,8 @@ struct vy_net {
     a.env_split_always_p1 = env_split_always + 1;
     a.env_wino_mode_p1 = env_wino_mode + 1;
     a.cus = cus;
+    a.ck_scratch = ck_bytes ? reinterpret_cast<float*>(dev_ws + ck_off) : nullptr;
+    a.ck_bytes = ck_bytes;
     a.splitk_slabs = reinterpret_cast<float*>(dev_ws + sk_off + al((size_t)VY_SK_FLAGS * sizeof(unsigned)));
     a.splitk_bytes = VY_SK_PARTIAL_BYTES;
     set_sk(a);
@@ -620,7 +638,10 @@ struct vy_net {
         }
         int bm, bn;
         vy_conv_cfg(a, &bm, &bn);
-        snprintf(nm, sizeof nm, "%s|%dx%d%s", c.name.c_str(), bm, bn, vy_conv_streamk(a) ? "sk" : "");
+        if (const int ks = vy_conv_ksplit(a))
+          snprintf(nm, sizeof nm, "%s|%dx%dks%d", c.name.c_str(), bm, bn, ks);
+        else
+          snprintf(nm, sizeof nm, "%s|%dx%d%s", c.name.c_str(), bm, bn, vy_conv_streamk(a) ? "sk" : "");
         hook(nm, fl, by, true);
         HIP_TRY(vy_launch_conv_igemm(a, s));
         hook(nm, fl, by, false);

@@ -33,9 +33,11 @@ struct SkItem {
   bool load_partial, store_partial;
 };
 
-// requires tiles >= nblk (every XCD's run then has at least as many tiles as blocks) and tiles * (nblk + 8) < 2^31
+// requires tiles >= nblk (every XCD's run then has at least as many tiles as blocks) and tiles * (nblk + 8) < 2^31.
+// align: every cut point (k0, k1) is a multiple of it — 1, or 4 for launches whose K is summed in runs (the run boundaries
+// of conv_tile sit at multiples of the LDS pipeline depth from a piece's first k-step); T_all must be a multiple of align.
 template <typename Div>
-VY_SK_HD SkSchedule sk_schedule(int nblk, int L, int tiles, int T_all, Div div) {
+VY_SK_HD SkSchedule sk_schedule(int nblk, int L, int tiles, int T_all, Div div, int align = 1) {
   SkSchedule s;
   const int q = nblk >> 3, r = nblk & 7, xcd = L & 7;
   s.l = L >> 3;
@@ -48,7 +50,8 @@ VY_SK_HD SkSchedule sk_schedule(int nblk, int L, int tiles, int T_all, Div div) 
   s.D = waves > 1 ? waves - 1 : 0;
   s.s0 = s.tx0 + s.D * s.gx;
   const int total = (nloc - s.D * s.gx) * T_all;                       // gx T_all <= total < 2 gx T_all
-  const int per = div((unsigned)(total + s.gx - 1), (unsigned)s.gx);   // T_all <= per < 2 T_all
+  int per = div((unsigned)(total + s.gx - 1), (unsigned)s.gx);         // T_all <= per < 2 T_all
+  if (align > 1) per = div((unsigned)(per + align - 1), (unsigned)align) * align;  // (<= 2 T_all: T_all % align == 0)
   const int it0 = s.l * per;
   const int it1 = it0 + per < total ? it0 + per : total;
   s.first = s.last = s.k0 = s.k1 = s.hb = s.w0 = s.nw = s.tail = s.tk1 = 0;
