@@ -371,12 +371,11 @@ def gather_detections(ids, scores, bboxes, total=None):
     if total is not None:
         sizes = split_sizes(int(total), w)
         if sizes[r] != int(packed.shape[0]):
-            # only THIS rank can see that its slice is wrong: the peers are about to enter the all-gather.  Abort the
-            # group so that they error out at once instead of waiting for the timeout, then raise
-            e = ValueError("rank %d holds %d frames of a batch of %d, expected %d" % (r, packed.shape[0], total, sizes[r]))
-            if w > 1:
-                fail_group(e)
-            raise e
+            # `total` and the slices must come from ONE decision every rank takes identically (HostFedDetector.submit checks
+            # len(clip_batch) == global_batch on every rank before anything is scattered): then this raises on all ranks
+            # together, before any collective, and the group stays usable.  A caller that passes a `total` only SOME ranks
+            # disagree with has left the others in the all-gather; they end with the group timeout (VY_DIST_TIMEOUT_S)
+            raise ValueError("rank %d holds %d frames of a batch of %d, expected %d" % (r, packed.shape[0], total, sizes[r]))
     else:
         sizes = [None] * w
         dist.all_gather_object(sizes, int(packed.shape[0]))
