@@ -117,7 +117,7 @@ bool g_labels_done = false;
 // Measurement aid (tools/ab_bn_bounds.sh): VY_TRAIN_ABL skips BatchNorm launches of the training step to BOUND what
 // fusing them into the neighbouring conv launches could return — bit 1: bn_bwd_reduce (+ its finalize), 2: the forward
 // bn_apply, 4: bn_bwd_apply; and, to see which stream of the backward pass holds the step, 8: no weight-gradient
-// kernels, 16: no data-gradient kernels.  The step then computes garbage; nothing else reads this.
+// kernels, 16: no data-gradient kernels, 32: no weight-gradient kernels for the early cells (N <= 128, K <= 576).  The step then computes garbage; nothing else reads this.
 // Compiled in ONLY with -DVY_TRAIN_ABL_BUILD (the A/B scripts build their own library): the shipped library never reads
 // the variable, so a leftover VY_TRAIN_ABL in somebody's environment cannot silently turn a training run into garbage.
 #ifdef VY_TRAIN_ABL_BUILD
@@ -649,8 +649,9 @@ int launch_wgrad(const TrainCtx& c, size_t ci, const float* dzp, int dz_cs, int 
   if (!g_labels_done) g_labels.note("wgrad", cv.name, w.M, w.Cout, (double)cv.k * cv.k * cv.cin);
   // conv mode VY_CONV_SPLIT_BF16X3_TRAIN: the split-fp32 weight-gradient kernel where it has the tile (Cout % 128 == 0)
   static const int wgrad_split = getenv("VY_SPLIT_WGRAD") ? atoi(getenv("VY_SPLIT_WGRAD")) : 1;
-  if (train_abl() & 8) {
-    // (bound measurement: no weight-gradient kernel at all)
+  if ((train_abl() & 8) || ((train_abl() & 32) && (long long)cv.k * cv.k * cv.cin <= 576 && cv.cout <= 128)) {
+    // (bound measurements: no weight-gradient kernel at all / none for the early cells — N <= 128, K <= 576: stages.0.1 ... 0.5 —
+    // whose output tile is mostly padding: what would a perfect kernel for them return to the step?)
   } else if (wgrad_split && net->conv_mode == VY_CONV_SPLIT_BF16X3_TRAIN && vy_wgrad_split_supported(w)) {
     HIP_TRY(vy_launch_wgrad_split(w, ws));
   } else {
