@@ -71,16 +71,23 @@ def _short_kernel_name(name):
     return name
 
 
-def _forward_tile_key(names, bm, bn, streamk=False):
-    """The counter file's name of the forward, double-buffered instance of a tile:
-    conv_igemm_kernel<BM, BN, WM, WN, DGRAD = false, NS = 2, SK = streamk> (older builds: 5 or 6 arguments)."""
+def _forward_tile_keys(names, bm, bn, streamk=False):
+    """The counter file's names of the forward, double-buffered instances of a tile:
+    conv_igemm_kernel<BM, BN, WM, WN, DGRAD = false, NS = 2, SK = streamk[, CK]> (older builds: 5, 6 or 7 arguments).  Two
+    since round 6: the launches whose K is summed in runs have their own instance (CK = true)."""
     pre = "void conv_igemm_kernel<%s, %s," % (bm, bn)
+    out = []
     for k in names:
         args = k[k.find("<") + 1:k.rfind(">")].replace(" ", "").split(",") if k.startswith(pre) else []
         if len(args) >= 5 and args[4] == "false" and (len(args) == 5 or args[5] == "2") \
                 and (len(args) > 6 and args[6] == "true") == bool(streamk):
-            return k
-    return None
+            out.append(k)
+    return out
+
+
+def _forward_tile_key(names, bm, bn, streamk=False):
+    keys = _forward_tile_keys(names, bm, bn, streamk)
+    return keys[0] if keys else None
 
 
 _PROFILER_ENV_PREFIXES = ("ROCP_", "ROCPROF", "ROCPROFILER_", "ROCTRACER_", "HSA_TOOLS_", "ROCTX_")
@@ -836,16 +843,21 @@ def main():
         if traffic:
             label = dom.split("<")[1].rstrip(">")  # "<BM>x<BN>" or "<BM>x<BN>sk" (stream-K instance)
             tile = label[:-2].split("x") if label.endswith("sk") else label.split("x")
-            key = _forward_tile_key(traffic, tile[0], tile[1], label.endswith("sk"))
-            if key:
-                result["roofline"]["traffic"] = traffic[key]["hbm_bytes"]
+            keys = _forward_tile_keys(traffic, tile[0], tile[1], label.endswith("sk"))
+            if keys:
+                # (launch-weighted over the instances the label covers: the launches summed in runs are a kernel of their own)
+                nl = float(sum(traffic[k]["launches"] for k in keys))
+                avg = lambda f: sum(traffic[k][f] * traffic[k]["launches"] for k in keys) / nl   # noqa: E731
+                key = keys[0]
+                result["roofline"]["traffic"] = avg("hbm_bytes")
                 result["roofline"]["traffic_detail"] = {
                     "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child runs of this command (FETCH x2: gfx950)",
-                    "fetch_bytes_per_launch": traffic[key]["fetch_bytes"], "write_bytes_per_launch": traffic[key]["write_bytes"],
-                    "over_algorithmic": traffic[key]["hbm_bytes"] / (by / n),
+                    "kernels": {k[:72]: {"launches_in_child_run": traffic[k]["launches"], "hbm_bytes_per_launch": traffic[k]["hbm_bytes"]} for k in keys},
+                    "fetch_bytes_per_launch": avg("fetch_bytes"), "write_bytes_per_launch": avg("write_bytes"),
+                    "over_algorithmic": avg("hbm_bytes") / (by / n),
                     "whole_step_hbm_bytes": traffic["_per_step"],
                     "other_kernels_MB_per_launch": {k[:48]: round(v["hbm_bytes"] / 1e6, 2) for k, v in traffic.items()
-                                                    if isinstance(v, dict) and k != key and "rocclr" not in k
+                                                    if isinstance(v, dict) and k not in keys and "rocclr" not in k
                                                     and "at::native" not in k}}
         if result["roofline"]["traffic"] is None:
             result["roofline"]["traffic_note"] = traffic_note
@@ -963,6 +975,12 @@ def main():
         from oracle import yolo3_oracle as O
         params = {p.name: p.data() for p in net.collect_params().values()}
         orc = O.OracleYolo3(args.classes, params)
+        try:  # one thread per physical core the host really grants (cpuset, cgroup quota): tools/cpu_torch_baseline.py
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import cpu_torch_baseline as ctb
+            O.lib().vyo_set_num_threads(int(ctb.child_env()["OMP_NUM_THREADS"]))
+        except Exception:
+            pass
         xs = x[:args.cpu_frames].cpu().numpy()
         t0 = time.perf_counter()
         orc(xs)

@@ -39,6 +39,16 @@
 #include <omp.h>
 #endif
 
+/* bench.py's cpu_baseline: as many threads as the host really grants (a cgroup CPU quota below the core count makes the
+ * default — one thread per logical CPU — thrash) */
+void vyo_set_num_threads(int n) {
+#ifdef _OPENMP
+  if (n > 0) omp_set_num_threads(n);
+#else
+  (void)n;
+#endif
+}
+
 int vyo_num_threads(void) {
 #ifdef _OPENMP
   return omp_get_max_threads();
