@@ -247,6 +247,7 @@ struct BnBwdArgs {
 int vy_bn_bwd_rows_per_chunk(int B, int H, int C);
 int vy_bn_bwd_chunks(const BnBwdArgs& a);
 hipError_t vy_launch_bn_bwd_reduce(const BnBwdArgs& a, hipStream_t s);
+void vy_bn_prio_init();   // reads VY_BN_PRIO once (train_kernels.hip: issue priority of the BatchNorm passes)
 struct BnBwdFinalizeArgs {
   const double* sums;     // [2][C]: sum dy, sum dy*xhat (all ranks when SyncBN)
   double count;

@@ -132,6 +132,25 @@ __device__ __forceinline__ void reduce2_finalize(const T* __restrict__ partials,
   }
 }
 
+// The BatchNorm passes of the backward pass run on the main stream BESIDE the weight-gradient kernels of the side stream
+// (train.hip).  Those hold two MFMA waves per SIMD, and fp32 MFMA shares the vector FMA hardware: a bandwidth-bound pass
+// whose waves get the pipe only between 64-cycle matrix instructions crawls (bn_bwd_reduce 17.6 us alone, 150 us beside
+// wgrad_kernel<32,128>).  s_setprio raises the issuing priority of these short waves: they take the few vector slots they
+// need and the matrix waves lose only those.  VY_BN_PRIO=0 (read once, copied to the device) turns it off for A/B.
+__device__ int g_bn_prio = 1;
+__device__ __forceinline__ void bn_raise_prio() {
+#if defined(__HIP_DEVICE_COMPILE__)
+  if (g_bn_prio) __builtin_amdgcn_s_setprio(3);
+#endif
+}
+void vy_bn_prio_init() {
+  static bool done = false;
+  if (done) return;
+  done = true;
+  const int v = getenv("VY_BN_PRIO") ? atoi(getenv("VY_BN_PRIO")) : 1;
+  if (v != 1) (void)hipMemcpyToSymbol(HIP_SYMBOL(g_bn_prio), &v, sizeof v);
+}
+
 __global__ __launch_bounds__(1024) void bn_reduce_finalize_kernel(const double* __restrict__ partials, int n_part,
                                                                   const BnFinalizeArgs a) {
   reduce2_finalize(partials, n_part, a,
@@ -199,6 +218,7 @@ hipError_t vy_launch_bn_finalize(const BnFinalizeArgs& a, hipStream_t s) {
 // ------------------------------------------------------------------------------------------------
 // grid: x over ceil(W*C/4 / 256), y over B*H rows.  One thread = 4 channels of one pixel.
 __global__ __launch_bounds__(256) void bn_apply_kernel(const BnApplyArgs a) {
+  bn_raise_prio();
   const int q = blockIdx.x * 256 + threadIdx.x;
   const int cq = a.C >> 2;
   if (q >= a.W * cq) return;
@@ -271,6 +291,7 @@ int vy_bn_bwd_rows_per_chunk(int B, int H, int C) {
 int vy_bn_bwd_chunks(const BnBwdArgs& a) { return (a.B * a.H + a.chunk - 1) / a.chunk; }
 
 __global__ __launch_bounds__(kBwdThreads) void bn_bwd_reduce_kernel(const BnBwdArgs a, int CQ) {
+  bn_raise_prio();
   __shared__ float red[2][kBwdThreads][4];
   const int PY = kBwdThreads / CQ;
   const int tq = threadIdx.x % CQ, py = threadIdx.x / CQ;
@@ -414,6 +435,7 @@ hipError_t vy_launch_bn_bwd_finalize(const BnBwdFinalizeArgs& a, hipStream_t s) 
 }
 
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdArgs a) {
+  bn_raise_prio();
   const int q = blockIdx.x * 256 + threadIdx.x;
   const int cq = a.C >> 2;
   if (q >= a.W * cq) return;
