@@ -339,3 +339,15 @@ def test_host_fed_detector_refuses_a_net_without_a_device(voc_classes):
     net = vy.yolo3_darknet53(voc_classes, pretrained_base=False)
     with pytest.raises(RuntimeError, match="reset_ctx"):
         stream.HostFedDetector(net, 4, (60, 80), 96)
+
+
+def test_detect_heads_needs_a_device_and_three_heads():
+    """net.detect_heads (vy_net_detect_heads: the detection tail alone on caller-supplied prediction tensors) refuses a net
+    whose parameters are not on a device — there is no CPU fallback — before it looks at the tensors."""
+    import numpy as np
+    import pytest
+    import videoyolo_amd as vy
+    net = vy.yolo3_darknet53(["a", "b", "c"], pretrained_base=False)
+    heads = [np.zeros((1, 24, 2, 2), np.float32), np.zeros((1, 24, 4, 4), np.float32), np.zeros((1, 24, 8, 8), np.float32)]
+    with pytest.raises(RuntimeError, match="not on a device"):
+        net.detect_heads(heads, 64)
