@@ -912,17 +912,10 @@ int vy_net_bind_train(vy_net* net, void* dev_ws, size_t bytes, int32_t batch, in
   net->sk_ok = vy_sk_verify_topology(reinterpret_cast<unsigned*>(net->dev_ws + net->sk_off), s) != 0;
   static const int use_side = getenv("VY_TRAIN_SIDE_STREAM") ? atoi(getenv("VY_TRAIN_SIDE_STREAM")) : 1;
   if (use_side && !t->side) {
-    // The weight-gradient stream at the LOWEST queue priority: workgroups of the main stream (BatchNorm passes, data
-    // gradients: the critical path of the backward pass — 13.7 ms of dependent work against 9.3 ms of weight gradients)
-    // are dispatched first when slots free up.  With the raised issue priority of the BatchNorm passes (train_kernels.hip):
-    // 522.4 -> 526.8 frames/s at 416x416 batch 16, same box, 3 x alternating (tools/ab_bn_prio.sh; each alone: +0.45 % /
-    // +0.0 %).  VY_SIDE_LOW_PRIO=0: default priority.
-    static const int low = getenv("VY_SIDE_LOW_PRIO") ? atoi(getenv("VY_SIDE_LOW_PRIO")) : 1;
-    int lo_p = 0, hi_p = 0;
-    if (low && hipDeviceGetStreamPriorityRange(&lo_p, &hi_p) == hipSuccess)
-      HIP_TRY(hipStreamCreateWithPriority(&t->side, hipStreamNonBlocking, lo_p));
-    else
-      HIP_TRY(hipStreamCreateWithFlags(&t->side, hipStreamNonBlocking));
+    // (The weight-gradient stream at the LOWEST queue priority was measured: +0.4 % on top of the raised issue priority of the
+    // BatchNorm passes in a fresh process — and the whole training step 1.55x SLOWER, forward included, in a process that had
+    // run the host-fed inference legs before (other streams alive: profiles/r06_ab_bn_prio.txt).  Default priority it stays.)
+    HIP_TRY(hipStreamCreateWithFlags(&t->side, hipStreamNonBlocking));
     vy_bn_prio_init();
     HIP_TRY(hipEventCreateWithFlags(&t->ev_main, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&t->ev_side, hipEventDisableTiming));
