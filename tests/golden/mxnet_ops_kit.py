@@ -115,7 +115,8 @@ def box_nms_cases():
         "nms_two_images_one_empty",
         "images are independent and an image without a valid row is all -1 (ref_ops.c:219-222)",
         np.concatenate([_rows([0, 0.9, 0, 0, 4, 4], [0, 0.8, 0, 0, 4, 3], [1, 0.7] + far(2)),
-                        _rows([0, 0.005] + far(0), [1, 0.01] + far(1), [2, 0.0] + far(2))]), valid_thresh=0.01))
+                        _rows([0, 0.005] + far(0), [1, 0.0075] + far(1), [2, 0.0] + far(2))]), valid_thresh=0.01))   # (no score ON the
+    # threshold here: tests/test_mxnet_kit_sensitivity.py found that a 0.01 in this case made it a second judge of strictness)
     out.append(_nms_case(
         "nms_degenerate_boxes",
         "zero-area and inverted boxes (include/vy_math.h vy_box_iou: no positive overlap -> 0, union <= 0 -> 0): two identical "
