@@ -136,3 +136,27 @@ def test_plus_one_iou_would_show_in_the_iou_cases():
     rows, ot, vt, topk, force = _nms_inputs(case, KIT.OracleOps())
     assert not np.array_equal(py_box_nms(rows, ot, vt, topk, force, **DEFAULTS),
                               py_box_nms(rows, ot, vt, topk, force, **dict(DEFAULTS, plus_one=True)))
+
+
+def test_running_variance_convention_would_show_in_the_cell_case():
+    """`conv_bn_leaky_train_step` decides biased vs unbiased running variance: with 2 x 4 x 4 = 32 samples per channel the
+    two conventions differ by var * 0.1 / 31 ~ 3e-3 of the running value — 300x the case's tolerance (1e-5)."""
+    case = next(c for c in KIT.all_cases() if c["op"] == "conv_bn_leaky")
+    ops = KIT.OracleOps()
+    base = ops.run(case["op"], case["inputs"], case["params"])["running_var"]
+    ops.TO.OracleYolo3Train.RUNNING_VAR_UNBIASED = True
+    try:
+        alt = ops.run(case["op"], case["inputs"], case["params"])["running_var"]
+    finally:
+        ops.TO.OracleYolo3Train.RUNNING_VAR_UNBIASED = False
+    assert np.abs(alt - base).min() > 1e-4, (base, alt)
+
+
+def test_loss_normalisation_would_show_in_the_loss_case():
+    """`yolov3_loss_pos_ignore_neg`: a per-element MEAN instead of the recalled mean x count (= per-sample sum) is off by the
+    anchor count (4) / channel count, far outside 1e-4."""
+    case = next(c for c in KIT.all_cases() if c["op"] == "yolov3_loss")
+    out = KIT.OracleOps().run(case["op"], case["inputs"], case["params"])
+    n = case["inputs"]["objness"].shape[1]
+    for k, v in out.items():
+        assert np.all(np.abs(v - v / n) > 1e-3 * np.maximum(np.abs(v), 1e-3)) or np.all(v == 0), (k, v)
