@@ -6,7 +6,6 @@ BatchNorm shift and input pixel zero (all matrix operands zero: the arithmetic i
 import argparse
 import os
 import sys
-import time
 
 import numpy as np
 

@@ -7,10 +7,7 @@ ROCm) / xGMI; ``gloo`` on CPU for the tests.  What shards:
               bucketed and overlapped with the backward pass (heads, stage 2, 1, 0);
               SyncBatchNorm layers all-reduce their [2][C] statistics forward and backward.
 """
-import ctypes
 import os
-
-import numpy as np
 
 
 def _dist():
