@@ -188,17 +188,31 @@ class LegWatchdog(object):
         import threading
         self.rank, self.budget, self.result = rank, float(budget_s), result
         self.leg, self.deadline = None, None
+        self.walls, self.t_leg, self.t0 = {}, None, time.time()   # wall-clock seconds per leg, for the line's `wall_s`
         self.lock = threading.Lock()
         if self.budget > 0:
             threading.Thread(target=self._run, daemon=True).start()
 
+    def _close(self, now):
+        if self.leg is not None and self.t_leg is not None:
+            self.walls[self.leg] = round(self.walls.get(self.leg, 0.0) + now - self.t_leg, 2)
+
     def arm(self, leg, scale=1.0):
         with self.lock:
-            self.leg, self.deadline = leg, time.time() + self.budget * scale
+            now = time.time()
+            self._close(now)
+            self.leg, self.deadline, self.t_leg = leg, now + self.budget * scale, now
 
     def disarm(self):
         with self.lock:
-            self.leg, self.deadline = None, None
+            self._close(time.time())
+            self.leg, self.deadline, self.t_leg = None, None, None
+
+    def wall_report(self):
+        """{"since_start": seconds since the bench built its watchdog (after import torch + init), "legs": {leg: seconds}}:
+        where the wall-clock time of THIS command went, so that the driver's own clock around the run can be reconciled"""
+        with self.lock:
+            return {"since_start": round(time.time() - self.t0, 2), "legs": dict(self.walls)}
 
     def _run(self):
         while True:
@@ -217,6 +231,7 @@ class LegWatchdog(object):
                     out = dict(self.result)
                     out[leg if leg != "headline" else "headline_leg"] = {"timeout": True, "budget_s": self.budget}
                     out["aborted_after_timeout_of"] = leg
+                    out["wall_s"] = {"since_start": round(time.time() - self.t0, 2), "legs": dict(self.walls)}
                     _emit(out)
                     break
                 except RuntimeError:   # the main thread was adding to the dict: take another copy
@@ -1077,6 +1092,7 @@ def main():
             result["also_syncbn608"] = leg
 
     dog.disarm()
+    result["wall_s"] = dog.wall_report()
     if rank == 0:
         _emit(result)
     if dist is not None:
@@ -1132,6 +1148,7 @@ def bench_train(args, vy, dev, dist, rank, world, traffic=None, traffic_note=Non
     if collective is not None:
         result["collective"] = collective
     dog.disarm()
+    result["wall_s"] = dog.wall_report()
     if rank == 0:
         _emit(result)
     if dist is not None:

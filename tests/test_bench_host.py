@@ -160,3 +160,23 @@ def test_leg_watchdog_prints_the_line_and_ends_the_run(tmp_path):
         if mode == "with_headline":
             assert line["value"] == 123.0 and line["also_416"] == {"frames_per_s": 1.0}
         assert "exceeded its wall-clock budget" in p.stderr.decode()
+
+
+def test_leg_watchdog_accounts_wall_clock_per_leg():
+    """`wall_s` of the line: seconds per leg between arm / arm / disarm (a leg armed twice accumulates), and since the start."""
+    import time
+    import bench
+    dog = bench.LegWatchdog(0, 0, {})       # budget 0: no thread, accounting only
+    dog.arm("headline")
+    time.sleep(0.05)
+    dog.arm("also_416")
+    time.sleep(0.02)
+    dog.disarm()
+    time.sleep(0.02)                        # between legs: counted in since_start only
+    dog.arm("headline")
+    time.sleep(0.03)
+    dog.disarm()
+    w = dog.wall_report()
+    assert set(w["legs"]) == {"headline", "also_416"}
+    assert 0.07 <= w["legs"]["headline"] <= 0.5 and 0.01 <= w["legs"]["also_416"] <= 0.3
+    assert w["since_start"] >= w["legs"]["headline"] + w["legs"]["also_416"]
