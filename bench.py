@@ -759,6 +759,10 @@ def main():
     collective = None
     if dist is not None:
         from videoyolo_amd import parallel
+        # the first collectives of the run (an all_gather_object, then the pre-flight) under their own watchdog: a fabric that
+        # hangs instead of failing ends the run with one line after at most 3 minutes, not after the group's timeout
+        pre = LegWatchdog(rank, min(args.leg_budget_s, 180.0), {"n_gpus": world, "error": "the first collectives of the run did not return"})
+        pre.arm("collective_preflight")
         collective = parallel.describe_group(dev)
         if not args.no_preflight:
             pf = parallel.preflight(dev, min_busbw_GBps=args.preflight_min_busbw if world > 1 else None)
@@ -769,6 +773,7 @@ def main():
                     _emit({"error": "collective pre-flight failed: " + pf["reason"], "n_gpus": world, "collective": collective})
                 dist.destroy_process_group()
                 sys.exit(3)
+        pre.disarm()
 
     if args.mode == "train":
         return bench_train(args, vy, dev, dist, rank, world, traffic, traffic_note, collective)
