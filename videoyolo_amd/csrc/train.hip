@@ -117,11 +117,22 @@ bool g_labels_done = false;
 // Measurement aid (tools/ab_bn_bounds.sh): VY_TRAIN_ABL skips BatchNorm launches of the training step to BOUND what
 // fusing them into the neighbouring conv launches could return — bit 1: bn_bwd_reduce (+ its finalize), 2: the forward
 // bn_apply, 4: bn_bwd_apply; and, to see which stream of the backward pass holds the step, 8: no weight-gradient
-// kernels, 16: no data-gradient kernels, 32: no weight-gradient kernels for the early cells (N <= 128, K <= 576).  The step then computes garbage; nothing else reads this.
+// kernels, 16: no data-gradient kernels, 32: no weight-gradient kernels for the early cells (N <= 128, K <= 576); 64 / 128: the
+// finalize launch between the backward / forward statistics reduce and its apply pass (tools/ab_bn_finalize.sh).  The step then
+// computes garbage; nothing else reads this.
 // Compiled in ONLY with -DVY_TRAIN_ABL_BUILD (the A/B scripts build their own library): the shipped library never reads
 // the variable, so a leftover VY_TRAIN_ABL in somebody's environment cannot silently turn a training run into garbage.
 #ifdef VY_TRAIN_ABL_BUILD
+// bits 64 / 128 (a finalize launch skipped: its outputs keep the previous step's values) only after VY_TRAIN_ABL_AFTER recorded
+// forwards (default 3), so that the planes never hold the all-zero data of a net whose statistics were never finalized
+static int g_abl_forwards = 0;
+static int train_abl_all();
 static int train_abl() {
+  static const int after = getenv("VY_TRAIN_ABL_AFTER") ? atoi(getenv("VY_TRAIN_ABL_AFTER")) : 3;
+  const int v = train_abl_all();
+  return g_abl_forwards > after ? v : (v & ~(64 | 128));
+}
+static int train_abl_all() {
   static const int v = [] {
     const int e = getenv("VY_TRAIN_ABL") ? atoi(getenv("VY_TRAIN_ABL")) : 0;
     if (e) fprintf(stderr, "libvyolo (VY_TRAIN_ABL_BUILD): VY_TRAIN_ABL=%d — training launches are being SKIPPED, gradients are garbage\n", e);
@@ -506,7 +517,7 @@ int forward_train(const TrainCtx& c, const float* x) {
     f.momentum = 0.9f;  // layers.py:68
     if (exchange)
       HIP_TRY(vy_launch_bn_finalize(f, c.s));
-    else
+    else if (!(train_abl() & 128))  // (128: the same for the forward statistics)
       HIP_TRY(vy_launch_bn_reduce_finalize(reinterpret_cast<const double*>(c.partials()), n_part, f, c.slice_sums(), c.s));
     BnApplyArgs ap;
     memset(&ap, 0, sizeof ap);
@@ -800,7 +811,7 @@ int backward_train(const TrainCtx& c, const float* x) {
       f.C = cv.cout;
       if (exchange)
         HIP_TRY(vy_launch_bn_bwd_finalize(f, c.s));
-      else if (!(train_abl() & 1))
+      else if (!(train_abl() & (1 | 64)))  // (64: the finalize launch alone skipped)
         HIP_TRY(vy_launch_bn_bwd_reduce_finalize(c.partials(), vy_bn_bwd_chunks(bb), f, c.s));
       if (!(train_abl() & 4)) HIP_TRY(vy_launch_bn_bwd_apply(bb, c.s));
       dzp = c.zplane(ci);
@@ -974,6 +985,9 @@ static int train_forward_impl(vy_net* net, const float* x, const float* gt_boxes
 int vy_net_train_forward(vy_net* net, const float* x, const float* gt_boxes, int32_t M, const float* obj_t,
                          const float* centers_t, const float* scales_t, const float* weights_t,
                          const float* clas_t, float* losses, void* stream) {
+#ifdef VY_TRAIN_ABL_BUILD
+  ++g_abl_forwards;
+#endif
   if (net)
     if (int rc = net->sk_begin(static_cast<hipStream_t>(stream))) return rc;
   const int rc = train_forward_impl(net, x, gt_boxes, M, obj_t, centers_t, scales_t, weights_t, clas_t, losses, stream);
