@@ -239,6 +239,46 @@ class LegWatchdog(object):
         os._exit(0 if "value" in self.result else 4)
 
 
+def device_under_load(torch, dev, run_step, steps=4, period_s=0.02):
+    """Clock, package power and temperature of the device WHILE the step runs: `steps` extra un-timed steps with a thread
+    sampling torch.cuda.clock_rate / power_draw / temperature (amdsmi) every 20 ms.  Boxes of a pool differ by a few percent
+    in what they sustain under this load (the same build read 945 - 987 frames/s during round 6); these figures let a reader
+    tell a slower box from a slower build.  None when the runtime has no such query."""
+    import threading
+    idx = dev.index if dev.index is not None else 0
+    try:
+        torch.cuda.clock_rate(idx)
+    except Exception as e:   # no amdsmi in this runtime
+        return {"error": "%s: %s" % (type(e).__name__, str(e)[:80])}
+    clk, pwr, tmp, stop = [], [], [], threading.Event()
+
+    def sample():
+        while not stop.is_set():
+            try:
+                clk.append(torch.cuda.clock_rate(idx))
+                pwr.append(torch.cuda.power_draw(idx))
+                tmp.append(torch.cuda.temperature(idx))
+            except Exception:
+                return
+            time.sleep(period_s)
+
+    th = threading.Thread(target=sample, daemon=True)
+    torch.cuda.synchronize(dev)
+    th.start()
+    for _ in range(steps):
+        run_step()
+    torch.cuda.synchronize(dev)
+    stop.set()
+    th.join(timeout=2.0)
+    if not clk:
+        return {"error": "no samples"}
+    med = lambda v: sorted(v)[len(v) // 2]   # noqa: E731
+    return {"sclk_mhz_median": med(clk), "sclk_mhz_min": min(clk), "sclk_mhz_max": max(clk), "power_median": med(pwr),
+            "power_unit": "as torch.cuda.power_draw reports it (W on this image; mW upstream)", "temperature_c_max": max(tmp),
+            "samples": len(clk), "steps": steps, "source": "torch.cuda.clock_rate / power_draw / temperature (amdsmi), sampled "
+            "every %d ms during %d extra un-timed steps of the headline workload" % (int(period_s * 1e3), steps)}
+
+
 def _emit(result):
     """the one line of the contract, on the process's REAL stdout (main() points fd 1 at stderr: library chatter)"""
     line = (json.dumps(result) + "\n").encode()
@@ -824,6 +864,7 @@ def main():
 
     dog.arm("roofline")
     if rank == 0 and not args.no_roofline:
+        result["device_under_load"] = device_under_load(torch, dev, lambda: net(x))
         # per-launch HIP-event timing of extra passes (same stream the kernels run on)
         med, agg = launch_table(net, x)
         # the dominant kernel: the implicit-GEMM tile variant with the largest share of the step

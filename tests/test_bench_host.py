@@ -180,3 +180,36 @@ def test_leg_watchdog_accounts_wall_clock_per_leg():
     assert set(w["legs"]) == {"headline", "also_416"}
     assert 0.07 <= w["legs"]["headline"] <= 0.5 and 0.01 <= w["legs"]["also_416"] <= 0.3
     assert w["since_start"] >= w["legs"]["headline"] + w["legs"]["also_416"]
+
+
+def test_device_under_load_samples_while_the_step_runs():
+    """`device_under_load` of the line: medians of the clock / power samples taken while the extra steps run; an error entry,
+    not an exception, on a runtime without the queries."""
+    import time
+    import types
+    import bench
+
+    class Cuda(object):
+        def __init__(self, ok=True):
+            self.ok, self.n = ok, 0
+
+        def clock_rate(self, i):
+            if not self.ok:
+                raise RuntimeError("amdsmi is not available")
+            self.n += 1
+            return 2300 + self.n % 3
+
+        def power_draw(self, i):
+            return 900
+
+        def temperature(self, i):
+            return 60
+
+        def synchronize(self, dev):
+            pass
+
+    dev = types.SimpleNamespace(index=0)
+    r = bench.device_under_load(types.SimpleNamespace(cuda=Cuda()), dev, lambda: time.sleep(0.03), steps=3, period_s=0.005)
+    assert r["samples"] >= 5 and 2300 <= r["sclk_mhz_median"] <= 2302 and r["power_median"] == 900 and r["temperature_c_max"] == 60
+    r = bench.device_under_load(types.SimpleNamespace(cuda=Cuda(ok=False)), dev, lambda: None)
+    assert "amdsmi is not available" in r["error"]
