@@ -132,6 +132,12 @@ bool vy_conv_split_pays(const ConvArgs& a);
 hipError_t vy_launch_conv_split(const ConvArgs& a, hipStream_t s);
 
 // stem: 3x3 stride-1 conv from the caller's NCHW image (Cin = 3) into a plane, fused affine+leaky.
+// BN fold: scale = gamma / sqrt(var + eps), shift = beta - mean*scale for n_layers BN layers.
+struct FoldDesc {
+  int64_t gamma, beta, mean, var;   // element offsets into the parameter buffer
+  int64_t scale, shift;             // element offsets into the parameter buffer (scratch region)
+  int32_t C, pad;
+};
 struct StemArgs {
   const float* x;       // (B,3,H,W) NCHW
   const float* w;       // [Cout][3][3][3]  (kh,kw,cin)
@@ -139,15 +145,20 @@ struct StemArgs {
   const float* shift;
   float* out;           // plane (B,H+2,W+2,out_cs)
   int B, H, W, Cout, out_cs, out_co;
+  // Inference only, optional: the eval-mode BatchNorm fold of the WHOLE net rides in this launch (the first of a forward)
+  // instead of a launch of its own in front of it — block i < fold_n folds layer i exactly as bn_fold_kernel does, and every
+  // lane takes the stem's own affine straight from its BatchNorm parameters (layer fold_stem; scale / shift are then not
+  // read).  8.5 us off the chain of one frame.  vy_launch_stem refuses (hipErrorInvalidValue) when the launch has fewer
+  // blocks than layers: ask vy_stem_can_fold first.
+  float* fold_params = nullptr;
+  const FoldDesc* fold_descs = nullptr;
+  int fold_n = 0, fold_stem = 0;
+  float fold_eps = 0.0f;
 };
 hipError_t vy_launch_stem(const StemArgs& a, hipStream_t s);
+bool vy_stem_can_fold(int B, int H, int W, int n_layers);   // the inference stem launch of this shape has >= n_layers blocks
 
-// BN fold: scale = gamma / sqrt(var + eps), shift = beta - mean*scale for n_layers BN layers.
-struct FoldDesc {
-  int64_t gamma, beta, mean, var;   // element offsets into the parameter buffer
-  int64_t scale, shift;             // element offsets into the parameter buffer (scratch region)
-  int32_t C, pad;
-};
+// (FoldDesc: above StemArgs)
 hipError_t vy_launch_bn_fold(float* params, const FoldDesc* descs_dev, int n_layers, int max_c,
                              float eps, hipStream_t s);
 

@@ -88,8 +88,23 @@ __global__ __launch_bounds__(256) void stem_kernel(const StemArgs a, double* __r
   }
   float sc = 1.0f, sh = 0.0f;
   if (!RAW) {
-    sc = a.scale[lrow];
-    sh = a.shift[lrow];
+    if (a.fold_descs) {  // the fold of the whole net rides in this launch (StemArgs): same operations as bn_fold_kernel
+      float* P = a.fold_params;
+      const FoldDesc d0 = a.fold_descs[a.fold_stem];
+      sc = vy_bn_scale(P[d0.gamma + lrow], P[d0.var + lrow], a.fold_eps);
+      sh = vy_bn_shift(P[d0.beta + lrow], P[d0.mean + lrow], sc);
+      if ((int)blockIdx.x < a.fold_n) {
+        const FoldDesc d = a.fold_descs[blockIdx.x];
+        for (int c = threadIdx.x; c < d.C; c += 256) {
+          const float fs = vy_bn_scale(P[d.gamma + c], P[d.var + c], a.fold_eps);
+          P[d.scale + c] = fs;
+          P[d.shift + c] = vy_bn_shift(P[d.beta + c], P[d.mean + c], fs);
+        }
+      }
+    } else {
+      sc = a.scale[lrow];
+      sh = a.shift[lrow];
+    }
   }
   __syncthreads();
   double s1 = 0.0, s2 = 0.0;
@@ -150,16 +165,35 @@ static hipError_t stem_check(const StemArgs& a) {
   return hipSuccess;
 }
 
+// rows per block of the inference launch
+static int stem_rows_infer(int B, int H, int W) {
+  int rows = stem_rows(W);
+  const int want = 2 * vy_cu_count();
+  while (rows > 1 && B * ((H + rows - 1) / rows) < want) rows >>= 1;
+  return rows;
+}
+
+bool vy_stem_can_fold(int B, int H, int W, int n_layers) {
+  const int rows = stem_rows_infer(B, H, W);
+  return B * ((H + rows - 1) / rows) >= n_layers;
+}
+
 hipError_t vy_launch_stem(const StemArgs& a, hipStream_t s) {
   if (stem_check(a) != hipSuccess) return hipErrorInvalidValue;
-  const int rows = stem_rows(a.W);
+  // A few frames: four rows per block leave most CUs without a block (one 608x608 frame: 152 blocks, 30 us for 47 MB);
+  // fewer rows per block until the launch has two blocks per CU (one frame: 608 blocks of one row, the input rows are
+  // then staged three times — 13 MB).  Every pixel's fma chain is the same whatever the strip height.  (The training
+  // launch below keeps the rule by width alone: its rows are also the layout of the statistics partials.)
+  const int rows = stem_rows_infer(a.B, a.H, a.W);
+  if (a.fold_descs && (!a.fold_params || a.fold_stem < 0 || a.fold_stem >= a.fold_n || !vy_stem_can_fold(a.B, a.H, a.W, a.fold_n)))
+    return hipErrorInvalidValue;
   const size_t lds = (size_t)3 * (rows + 2) * (((a.W + 31) & ~31) + 8) * sizeof(float);
   if (lds > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_kernel<false>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
   }
-  hipLaunchKernelGGL(stem_kernel<false>, dim3(vy_stem_blocks(a.B, a.H, a.W)), dim3(256), lds, s, a, nullptr, rows);
+  hipLaunchKernelGGL(stem_kernel<false>, dim3(a.B * ((a.H + rows - 1) / rows)), dim3(256), lds, s, a, nullptr, rows);
   return hipGetLastError();
 }
 

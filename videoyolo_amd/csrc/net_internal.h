@@ -569,9 +569,16 @@ struct vy_net {
       HIP_TRY(hipStreamSynchronize(s));  // `folds` is pageable host memory; one-time
       fold_uploaded = true;
     }
-    hook("bn_fold", 0.0, 0.0, true);
-    HIP_TRY(vy_launch_bn_fold(dev_params, fd, (int)folds.size(), 1024, 1e-5f, s));
-    hook("bn_fold", 0.0, 0.0, false);
+    // The fold runs EVERY forward (the caller owns the parameter buffer and may have written to it) — inside the stem launch
+    // when that has a block per layer (StemArgs), in a launch of its own otherwise.  VY_FOLD_IN_STEM=0: always its own.
+    static const int fold_in_stem_on = getenv("VY_FOLD_IN_STEM") ? atoi(getenv("VY_FOLD_IN_STEM")) : 1;
+    const bool fold_in_stem = fold_in_stem_on && !convs.empty() && convs[0].is_stem && convs[0].scale_off == folds[0].scale &&
+                              vy_stem_can_fold(B, H, W, (int)folds.size());
+    if (!fold_in_stem) {
+      hook("bn_fold", 0.0, 0.0, true);
+      HIP_TRY(vy_launch_bn_fold(dev_params, fd, (int)folds.size(), 1024, 1e-5f, s));
+      hook("bn_fold", 0.0, 0.0, false);
+    }
     if (conv_mode != VY_CONV_EXACT_FP32 && (split_dirty || wino_dirty)) {  // once per parameter change, not per forward
       hook("split_weights", 0.0, 0.0, true);
       for (const ConvT& c : convs)
@@ -599,6 +606,13 @@ struct vy_net {
         a.Cout = c.cout;
         a.out_cs = planes[c.out_plane].C;
         a.out_co = c.out_co;
+        if (fold_in_stem) {
+          a.fold_params = dev_params;
+          a.fold_descs = fd;
+          a.fold_n = (int)folds.size();
+          a.fold_stem = 0;
+          a.fold_eps = 1e-5f;
+        }
         const double fl = 2.0 * B * H * W * 27.0 * c.cout;
         const double by = 4.0 * B * H * W * (3.0 + c.cout);
         hook(c.name.c_str(), fl, by, true);
